@@ -1,0 +1,228 @@
+/*
+ * mhh_hip.h -- C ABI of the MI355X-native RHS + pressure hot path (libmhh_hip.so).
+ *
+ * Drop-in boundary for the reference's Advec / Diff / Pres / Boundary_cyclic operators
+ * (adconnolly/microhh). The reference has no FFI; its GPU seam is the set of member
+ * functions that the .cu files re-define under USECUDA. Every entry point below names the
+ * reference member function / kernel it replaces (paths relative to the reference root).
+ * INTEGRATION.md shows the adaptor TU a MicroHH maintainer would add.
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in signatures; `stream` is a hipStream_t passed as void*
+ *     (NULL = default stream). Nothing here synchronises the device unless stated.
+ *   - all field pointers are DEVICE pointers, layout identical to the reference's host layout:
+ *     ijk = i + j*icells + k*ijcells, i fastest, ghost cells included (include/grid.h:70-80).
+ *   - element type is selected by mhh_grid.dtype (MHH_F64 = reference default build,
+ *     MHH_F32 = reference -DUSESP build). Scalars cross the ABI as double and are narrowed
+ *     exactly where the reference narrows them.
+ *   - return value: 0 = ok, otherwise an MHH_E* code; mhh_last_error() gives the text. The C++
+ *     adaptor turns non-zero into std::runtime_error like the reference host code does
+ *     (include/tools.h:49-56, src/pres.cu:185-186).
+ *   - buffers are owned by the caller (Field3d::init_device, src/field3d.cu:32-47); kernels
+ *     borrow and never retain pointers. Not re-entrant per plan object.
+ */
+#ifndef MHH_HIP_H
+#define MHH_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MHH_F64 0
+#define MHH_F32 1
+
+#define MHH_OK        0
+#define MHH_EINVAL    1   /* bad argument / unsupported combination */
+#define MHH_EHIP      2   /* HIP runtime error */
+#define MHH_EFFT      3   /* rocFFT error (reference: runtime_error("FFT error")) */
+#define MHH_ENOMEM    4
+
+/* Boundary_cyclic Edge (include/boundary_cyclic.h:33) */
+#define MHH_EDGE_EW   0
+#define MHH_EDGE_NS   1
+#define MHH_EDGE_BOTH 2
+
+/* advection schemes (src/advec.cxx:55-83 swadvec) */
+#define MHH_ADVEC_2    2
+#define MHH_ADVEC_2I5  25
+#define MHH_ADVEC_4    4
+/* diffusion schemes (src/diff.cxx:57-85 swdiff) */
+#define MHH_DIFF_2     2
+#define MHH_DIFF_4     4
+#define MHH_DIFF_SMAG2 22
+
+/* Mirror of Grid_data<TF> (include/grid.h:49-135) reduced to what the hot path reads.
+ * Metric arrays are device pointers of kcells elements of the grid's dtype. */
+typedef struct mhh_grid
+{
+    int itot, jtot, ktot;
+    int imax, jmax, kmax;          /* per-rank interior; == itot,jtot,ktot on one GPU   */
+    int igc, jgc, kgc;
+    int icells, jcells, ijcells, kcells;
+    int istart, jstart, kstart;
+    int iend, jend, kend;
+    int dtype;                     /* MHH_F64 | MHH_F32                                  */
+    int npx, npy;                  /* slab decomposition: npx must be 1                   */
+    int mpicoordx, mpicoordy;      /* rank coordinates (include/master.h:34-53)           */
+    long long ncells;
+    double xsize, ysize, zsize;
+    double dx, dy;
+    const void* z;
+    const void* zh;
+    const void* dz;
+    const void* dzh;
+    const void* dzi;
+    const void* dzhi;
+    const void* dzi4;
+    const void* dzhi4;
+} mhh_grid;
+
+#define MHH_MAX_SCALARS 8
+
+/* Mirror of the slice of Fields<TF> the operators touch (include/fields.h:132-161):
+ * mp (u,v,w), mt (ut,vt,wt), sp/st (scalars and their tendencies), sd["evisc"], sd["p"],
+ * rhoref/rhorefh, and the 2-D surface arrays consumed by diff_smag2. NULL where unused. */
+typedef struct mhh_fields
+{
+    void* u;  void* v;  void* w;
+    void* ut; void* vt; void* wt;
+    int   nscalars;
+    void* s [MHH_MAX_SCALARS];
+    void* st[MHH_MAX_SCALARS];
+    double svisc[MHH_MAX_SCALARS];   /* Field3d::visc of each scalar                      */
+    void* evisc;
+    void* p;
+    const void* rhoref;              /* [kcells] */
+    const void* rhorefh;             /* [kcells] */
+    double visc;                     /* Fields::visc                                       */
+    /* surface model inputs (Boundary_surface outputs; NULL => resolved walls, "default") */
+    const void* u_fluxbot; const void* u_fluxtop;
+    const void* v_fluxbot; const void* v_fluxtop;
+    const void* s_fluxbot[MHH_MAX_SCALARS]; const void* s_fluxtop[MHH_MAX_SCALARS];
+    const void* dudz; const void* dvdz; const void* dbdz;   /* boundary.get_dudz() etc.    */
+    const void* z0m;
+} mhh_fields;
+
+const char* mhh_last_error(void);
+int mhh_version(void);
+
+/* ---- Boundary_cyclic -------------------------------------------------------------------
+ * replaces Boundary_cyclic<TF>::exec_g / exec (src/boundary_cyclic.cu:91-127,
+ * src/boundary_cyclic.cxx:370-443) and exec_2d(_g) (:445-500). jtot==1 replicates row. */
+int mhh_boundary_cyclic   (const mhh_grid* g, void* data, int edge, void* stream);
+int mhh_boundary_cyclic_2d(const mhh_grid* g, void* data, void* stream);
+/* several fields in one launch (Boundary::set_prognostic_cyclic_bcs, src/boundary.cxx:447-458) */
+int mhh_boundary_cyclic_n (const mhh_grid* g, void* const* data, int nfields, int edge, void* stream);
+
+/* ---- Advection (kernel granularity of the reference) -----------------------------------
+ * scheme 2  : src/advec_2.cxx:81-202   (advec_u/v/w/s),  GPU src/advec_2.cu:38-117
+ * scheme 25 : src/advec_2i5.cxx:151-728,                 GPU src/advec_2i5.cu:41-510
+ * scheme 4  : src/advec_4.cxx:88-486,                    GPU src/advec_4.cu:37-442
+ * Each call adds the advective tendency of one field (read-modify-write of the tendency). */
+int mhh_advec_u(const mhh_grid* g, int scheme, void* ut, const void* u, const void* v, const void* w,
+                const void* rhoref, const void* rhorefh, void* stream);
+int mhh_advec_v(const mhh_grid* g, int scheme, void* vt, const void* u, const void* v, const void* w,
+                const void* rhoref, const void* rhorefh, void* stream);
+int mhh_advec_w(const mhh_grid* g, int scheme, void* wt, const void* u, const void* v, const void* w,
+                const void* rhoref, const void* rhorefh, void* stream);
+int mhh_advec_s(const mhh_grid* g, int scheme, void* st, const void* s, const void* u, const void* v, const void* w,
+                const void* rhoref, const void* rhorefh, void* stream);
+/* Advec::exec (src/advec_2.cxx:297-335, advec_2i5.cxx:977-1044, advec_4.cxx:592-650) */
+int mhh_advec_exec(const mhh_grid* g, int scheme, const mhh_fields* f, void* stream);
+/* calc_cfl + Master::max + *dt  (src/advec_2.cxx:51-78, advec_2i5.cxx:60-148, advec_4.cxx:51-86);
+ * *cfl_out is a host double; the call synchronises `stream`. `work` = device scratch of
+ * mhh_reduce_work_bytes() bytes. */
+int mhh_advec_cfl(const mhh_grid* g, int scheme, const void* u, const void* v, const void* w,
+                  double dt, void* work, double* cfl_out, void* stream);
+unsigned long long mhh_reduce_work_bytes(void);
+
+/* ---- Diffusion ---------------------------------------------------------------------------
+ * diff_2: src/diff_2.cxx:39-86 (diff_c, diff_w)   GPU src/diff_2.cu:34-90
+ * diff_4: src/diff_4.cxx:41-173                   GPU src/diff_4.cu:37-160          */
+int mhh_diff_c(const mhh_grid* g, int order, void* at, const void* a, double visc, void* stream);
+int mhh_diff_w(const mhh_grid* g, int order, void* wt, const void* w, double visc, void* stream);
+
+/* diff_smag2 (src/diff_smag2.cxx; parity target is the CPU path, NOT src/diff_smag2.cu, see
+ * DESIGN.md). surface_model = 1 <=> boundary.get_switch() != "default".                  */
+int mhh_smag2_strain2(const mhh_grid* g, int surface_model, void* strain2,
+                      const void* u, const void* v, const void* w,
+                      const void* dudz, const void* dvdz, void* stream);                 /* :47-155  */
+int mhh_smag2_evisc(const mhh_grid* g, int surface_model, void* evisc, const void* N2,
+                    const void* bgradbot, const void* z0m, double cs, double tPr, void* stream); /* :254-367 incl. cyclic fill */
+int mhh_smag2_evisc_neutral(const mhh_grid* g, int surface_model, void* evisc,
+                    const void* u, const void* v, const void* z0m,
+                    double cs, double visc, void* stream);                               /* :157-252 incl. cyclic fill */
+int mhh_smag2_diff_u(const mhh_grid* g, int surface_model, void* ut, const void* u, const void* v, const void* w,
+                     const void* evisc, const void* fluxbot, const void* fluxtop,
+                     const void* rhoref, const void* rhorefh, double visc, void* stream); /* :369-468 */
+int mhh_smag2_diff_v(const mhh_grid* g, int surface_model, void* vt, const void* u, const void* v, const void* w,
+                     const void* evisc, const void* fluxbot, const void* fluxtop,
+                     const void* rhoref, const void* rhorefh, double visc, void* stream); /* :470-571 */
+int mhh_smag2_diff_w(const mhh_grid* g, void* wt, const void* u, const void* v, const void* w,
+                     const void* evisc, const void* rhoref, const void* rhorefh, double visc, void* stream); /* :573-617 */
+int mhh_smag2_diff_c(const mhh_grid* g, int surface_model, void* at, const void* a,
+                     const void* evisc, const void* fluxbot, const void* fluxtop,
+                     const void* rhoref, const void* rhorefh, double tPr, double visc, void* stream); /* :619-709 */
+int mhh_smag2_dnmul(const mhh_grid* g, const void* evisc, double tPr, void* work,
+                    double* dnmul_out, void* stream);                                      /* :711-736 + master.max */
+/* Thermo_dry calc_N2 hook (src/thermo_dry.cxx:66-78): input of calc_evisc */
+int mhh_calc_N2(const mhh_grid* g, void* N2, const void* th, const void* thref, double grav, void* stream);
+
+/* Diff::exec_viscosity / Diff::exec (src/diff_smag2.cxx:1046-1188, :939-1043; diff_2.cxx:150-180;
+ * diff_4.cxx:262-300). For smag2, N2 (3-D) must be supplied unless `th_for_N2` >= 0, in which case
+ * N2 is evaluated inline from scalar th_for_N2 with thref/grav (fusion of thermo.get_thermo_field). */
+typedef struct mhh_diff_params
+{
+    double cs, tPr;          /* [diff] cs, tPr  (src/diff_smag2.cxx:853-855)              */
+    int    surface_model;    /* boundary switch != "default"                               */
+    int    neutral;          /* thermo switch == "0"                                       */
+    const void* N2;          /* 3-D buoyancy frequency, or NULL with th_for_N2 >= 0        */
+    int    th_for_N2;
+    const void* thref;       /* [kcells]                                                   */
+    double grav;
+} mhh_diff_params;
+int mhh_diff_exec_viscosity(const mhh_grid* g, int scheme, const mhh_fields* f, const mhh_diff_params* p, void* stream);
+int mhh_diff_exec(const mhh_grid* g, int scheme, const mhh_fields* f, const mhh_diff_params* p, void* stream);
+
+/* ---- Fused RHS: advec.exec + diff.exec in one pass over the tendencies ------------------
+ * Same arithmetic, same order of accumulation into each tendency as calling
+ * mhh_advec_exec then mhh_diff_exec (bit-identical results), one read of every input
+ * and one read-modify-write of every tendency. Supported pairs: (2,2) (25,22) (4,4).    */
+int mhh_rhs_exec(const mhh_grid* g, int advec_scheme, int diff_scheme, const mhh_fields* f,
+                 const mhh_diff_params* p, void* stream);
+
+/* ---- Pressure ----------------------------------------------------------------------------
+ * Plan object = Pres_2 / Pres_4 private state: bmati/bmatj, a/c (m1..m7), rocFFT plans,
+ * work buffers (Pres_2::init/set_values/prepare_device: src/pres_2.cxx:107-153,
+ * src/pres_2.cu:217-240; pres_4.cxx:179-252).  rhoref/rhorefh/dz/dzhi(/dzi4/dzhi4) are read at
+ * creation through HOST pointers (set_values runs on the host in the reference too).       */
+typedef struct mhh_pres_plan mhh_pres_plan;
+int  mhh_pres_plan_create(const mhh_grid* g, int order /*2|4*/,
+                          const void* host_dz, const void* host_dzhi,
+                          const void* host_dzi4, const void* host_dzhi4,
+                          const void* host_rhoref, const void* host_rhorefh,
+                          mhh_pres_plan** out);
+void mhh_pres_plan_destroy(mhh_pres_plan* plan);
+/* Pres::exec(dt): input -> solve -> output (src/pres_2.cxx:66-94, pres_4.cxx:64-140) */
+int mhh_pres_exec(mhh_pres_plan* plan, const mhh_grid* g, const mhh_fields* f, double dt, void* stream);
+/* stages, exposed for the slab-decomposed driver and for parity tests */
+int mhh_pres_input (mhh_pres_plan* plan, const mhh_grid* g, const mhh_fields* f, double dt, void* p_packed, void* stream); /* pres_2.cxx:156-196, pres_4.cxx:256-317 */
+int mhh_pres_solve (mhh_pres_plan* plan, const mhh_grid* g, const mhh_fields* f, void* p_packed, void* stream);            /* pres_2.cxx:267-362, pres_4.cxx:320-529 */
+int mhh_pres_output(mhh_pres_plan* plan, const mhh_grid* g, const mhh_fields* f, void* stream);                            /* pres_2.cxx:365-387, pres_4.cxx:533-571 */
+/* Pres::check_divergence (src/pres_2.cxx:391-422, pres_4.cxx:733-767); synchronises stream */
+int mhh_pres_check_divergence(const mhh_grid* g, int order, const mhh_fields* f, void* work, double* div_out, void* stream);
+
+/* slab-decomposed (npy>1) pressure stages: local pieces either side of the x<->y all-to-all
+ * (Transpose::exec_xy / exec_yx, src/transpose.cxx:170-219). Buffers are packed
+ * [rank-block][k][j][i] so that one all_to_all_single moves them.                          */
+int mhh_pres_fwd_x_pack (mhh_pres_plan* plan, const mhh_grid* g, void* p_packed, void* sendbuf, void* stream);
+int mhh_pres_fwd_y_solve_bwd_y(mhh_pres_plan* plan, const mhh_grid* g, void* recvbuf, void* sendbuf, void* stream);
+int mhh_pres_bwd_x_unpack(mhh_pres_plan* plan, const mhh_grid* g, void* recvbuf, const mhh_fields* f, void* stream);
+
+/* ---- Timeloop RK3/RK4 substep (src/timeloop.cxx:250-334, src/timeloop.cu:35-122) -------- */
+int mhh_rk_substep(const mhh_grid* g, int rkorder, int substep, double dt, void* a, void* at, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MHH_HIP_H */
