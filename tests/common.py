@@ -73,7 +73,7 @@ class Case:
     numpy.random.seed(666), uniform [0,1) fields in the order u, v, w, s, then rhoref, rhorefh), on a
     PHYSICAL grid instead of random metrics."""
 
-    def __init__(self, grid, seed=666, nscalars=1, rho="random", tend_scale=1e-3, vel_shift=0.5):
+    def __init__(self, grid, seed=666, nscalars=1, rho="random", tend_scale=1e-3, vel_shift=0.5, periodic=False):
         self.grid = g = grid
         t = g.np_dtype
         rs = np.random.RandomState(seed)
@@ -112,6 +112,10 @@ class Case:
         self.v_fluxbot = f2(1e-2); self.v_fluxtop = f2(1e-2)
         self.s_fluxbot = f2(1e-2); self.s_fluxtop = f2(1e-2)
         self.p = np.zeros(n3, dtype=t)
+        if periodic:   # what Boundary::set_prognostic_cyclic_bcs leaves behind (src/boundary.cxx:447-458)
+            G = g.host_struct()
+            for a in [self.u, self.v, self.w] + self.s:
+                oracle().orc_boundary_cyclic(G, ptr(a), EDGE_BOTH)
 
     def copy_of(self, name):
         a = getattr(self, name)
