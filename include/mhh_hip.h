@@ -147,11 +147,15 @@ int mhh_diff_w(const mhh_grid* g, int order, void* wt, const void* w, double vis
 int mhh_smag2_strain2(const mhh_grid* g, int surface_model, void* strain2,
                       const void* u, const void* v, const void* w,
                       const void* dudz, const void* dvdz, void* stream);                 /* :47-155  */
+/* mlen0[kcells] = cs*pow(dx*dy*dz[k],1/3) is a per-level table computed on the HOST with the C library's pow
+ * (mhh_smag2_mlen0_host; `g` then carries HOST metric pointers) and uploaded by the caller -- what
+ * Diff_smag2::prepare_device does in the reference's GPU path (src/diff_smag2.cu:521-542).               */
+int mhh_smag2_mlen0_host(const mhh_grid* g_host, double cs, void* mlen0_host_out);
 int mhh_smag2_evisc(const mhh_grid* g, int surface_model, void* evisc, const void* N2,
-                    const void* bgradbot, const void* z0m, double cs, double tPr, void* stream); /* :254-367 incl. cyclic fill */
+                    const void* bgradbot, const void* z0m, const void* mlen0, double tPr, void* stream); /* :254-367 incl. cyclic fill */
 int mhh_smag2_evisc_neutral(const mhh_grid* g, int surface_model, void* evisc,
                     const void* u, const void* v, const void* z0m,
-                    double cs, double visc, void* stream);                               /* :157-252 incl. cyclic fill */
+                    const void* mlen0, double visc, void* stream);                       /* :157-252 incl. cyclic fill */
 int mhh_smag2_diff_u(const mhh_grid* g, int surface_model, void* ut, const void* u, const void* v, const void* w,
                      const void* evisc, const void* fluxbot, const void* fluxtop,
                      const void* rhoref, const void* rhorefh, double visc, void* stream); /* :369-468 */
@@ -180,6 +184,7 @@ typedef struct mhh_diff_params
     int    th_for_N2;
     const void* thref;       /* [kcells]                                                   */
     double grav;
+    const void* mlen0;       /* [kcells] device table from mhh_smag2_mlen0_host            */
 } mhh_diff_params;
 int mhh_diff_exec_viscosity(const mhh_grid* g, int scheme, const mhh_fields* f, const mhh_diff_params* p, void* stream);
 int mhh_diff_exec(const mhh_grid* g, int scheme, const mhh_fields* f, const mhh_diff_params* p, void* stream);

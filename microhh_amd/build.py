@@ -1,0 +1,49 @@
+"""Build libmhh_hip.so: hand-written HIP kernels + C-ABI, cross-compiled for gfx950 with hipcc.
+
+    python -m microhh_amd.build            # strict build (default): -ffp-contract=off, bit-exact stencils
+The .so is written in-tree (microhh_amd/libmhh_hip.so) so that it travels with the repo snapshot.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SOURCES = ["k_stencil.hip", "k_rhs.hip", "k_pres.hip"]
+LIB = os.path.join(HERE, "libmhh_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# -ffp-contract=off: no FMA contraction, so that every stencil rounds like the reference CPU path built
+# with the same setting (DESIGN.md "Parity").
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
+          "-Wall", "-Wno-unused-function", "-I/opt/rocm/include", "-I" + CSRC]
+
+
+def _newer(src, dst):
+    return (not os.path.exists(dst)) or os.path.getmtime(src) > os.path.getmtime(dst)
+
+
+def build(force=False, verbose=True):
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "mhh_hip.h")]
+    objs, jobs = [], []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(CSRC, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _newer(src, obj) or any(_newer(d, obj) for d in deps):
+            jobs.append([HIPCC] + CFLAGS + ["-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    if jobs or not os.path.exists(LIB):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lrocfft", "-Wl,-rpath,/opt/rocm/lib"])
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

@@ -1,0 +1,477 @@
+// cell_ops.h -- per-cell arithmetic of the RHS operators (advec_2 / advec_2i5 / advec_4, diff_2 / diff_4 /
+// diff_smag2, pres in/out) as __host__ __device__ inline functions.
+//
+// Every function returns the increment(s) the reference adds to ONE tendency cell, with the reference's
+// expression association (file:line cited per function, paths relative to the reference root), so that
+// with -ffp-contract=off the HIP kernels are bit-identical to the reference CPU path in fp64 and fp32.
+// The functions take a pointer + flat index + strides, so the same body serves one-cell-per-thread
+// kernels and the fused multi-tendency kernels. Compiling this header with a host compiler
+// (MHH_HD empty) is how tests/emul checks the arithmetic on the CPU before any GPU time is spent.
+#pragma once
+#include <cmath>
+
+#if defined(__HIPCC__)
+#  define MHH_HD __host__ __device__ __forceinline__
+#else
+#  define MHH_HD inline
+#endif
+
+namespace mhh
+{
+// Kernel-side grid descriptor (subset of Grid_data, include/grid.h:49-135, narrowed to TF on the host).
+template<class TF>
+struct GridDev
+{
+    int itot, jtot, ktot, imax, jmax, kmax, igc, jgc, kgc;
+    int icells, jcells, ijcells, kcells;
+    int istart, iend, jstart, jend, kstart, kend;
+    int dim3;                 // jtot != 1 (Advec_4::exec, src/advec_4.cxx:596)
+    TF dx, dy, zsize;
+    TF dxi_t, dyi_t;          // TF(1.)/dx : spelling of advec_*, pres_2  (TF quotient)
+    TF dxi_d, dyi_d;          // TF(1./dx) : spelling of diff_smag2, pres_4, calc_cfl of advec_2/2i5 (double quotient, narrowed)
+    TF dxidxi_d, dyidyi_d;    // TF(1./(dx*dx)): diff_smag2 diff_c / dnmul, diff_4 diff_c
+    TF dxidxi_t, dyidyi_t;    // TF(1/(dx*dx)) : diff_4 diff_w
+    double dxidxi_2, dyidyi_2;// double(TF(1)/(dx*dx)): diff_2 (src/diff_2.cxx:44-45, a double even in SP builds)
+    const TF* z; const TF* dz; const TF* dzi; const TF* dzhi; const TF* dzi4; const TF* dzhi4;
+};
+
+MHH_HD double tabs(double a) { return __builtin_fabs(a); }
+MHH_HD float  tabs(float a)  { return __builtin_fabsf(a); }
+template<class TF> MHH_HD TF tmin(TF a, TF b) { return (b < a) ? b : a; }   // std::min semantics
+template<class TF> MHH_HD TF tmax(TF a, TF b) { return (a < b) ? b : a; }   // std::max semantics
+template<class TF> MHH_HD TF sq(TF a) { return a*a; }
+
+// ---- interpolation weights (include/finite_difference.h:36-155) -------------------------------------
+template<class TF> MHH_HD TF i2(TF a, TF b) { return TF(0.5)*(a+b); }
+template<class TF> MHH_HD TF i6(TF a, TF b, TF c, TF d, TF e, TF f)
+{ return TF(37./60.)*(c+d) - TF(8./60.)*(b+e) + TF(1./60.)*(a+f); }
+template<class TF> MHH_HD TF i5(TF a, TF b, TF c, TF d, TF e, TF f)
+{ return TF(10./60.)*(d-c) - TF(5./60.)*(e-b) + TF(1./60.)*(f-a); }
+template<class TF> MHH_HD TF i4ws(TF a, TF b, TF c, TF d) { return TF(7./12.)*(b+c) - TF(1./12.)*(a+d); }
+template<class TF> MHH_HD TF i3ws(TF a, TF b, TF c, TF d) { return TF(3./12.)*(c-b) - TF(1./12.)*(d-a); }
+
+#define MHH_W4(name, w0, w1, w2, w3) \
+    template<class TF> MHH_HD TF name(TF a, TF b, TF c, TF d) { return TF(w0)*a + TF(w1)*b + TF(w2)*c + TF(w3)*d; }
+MHH_W4(ci4, -1./16.,  9./16.,  9./16., -1./16.)
+MHH_W4(bi4,  5./16., 15./16., -5./16.,  1./16.)
+MHH_W4(ti4,  1./16., -5./16., 15./16.,  5./16.)
+MHH_W4(cg4,  1./24., -27./24., 27./24., -1./24.)
+MHH_W4(bg4, -23./24., 21./24.,  3./24., -1./24.)
+MHH_W4(tg4,  1./24., -3./24., -21./24., 23./24.)
+#undef MHH_W4
+template<class TF> MHH_HD TF i4c(TF a, TF b, TF c, TF d) { return TF(-1./16.)*(a+d) + TF(9./16.)*(b+c); }
+
+// =======================================================================================================
+// advec_2 (src/advec_2.cxx:81-202). COMP: 0=u 1=v 2=w (momentum, staggering offset o = -1/-jj/-kk), 3=scalar.
+// rt/rb/rc/dz are the face/cell density weights and the metric of the row k (chosen by the caller):
+//   u,v,s: rt=rhorefh[k+1] rb=rhorefh[k] rc=rhoref[k] dz=dzi[k];  w: rt=rhoref[k] rb=rhoref[k-1] rc=rhorefh[k] dz=dzhi[k]
+// =======================================================================================================
+template<class TF>
+MHH_HD TF advec2_mom(const TF* __restrict__ f, const TF* __restrict__ u, const TF* __restrict__ v, const TF* __restrict__ w,
+                     int c, int o, int jj, int kk, TF dxi, TF dyi, TF rt, TF rb, TF rc, TF dz)
+{
+    return
+        - ( i2(u[c+1+o], u[c+1]) * i2(f[c], f[c+1])
+          - i2(u[c  +o], u[c  ]) * i2(f[c-1], f[c]) ) * dxi
+        - ( i2(v[c+jj+o], v[c+jj]) * i2(f[c], f[c+jj])
+          - i2(v[c   +o], v[c   ]) * i2(f[c-jj], f[c]) ) * dyi
+        - ( rt * i2(w[c+kk+o], w[c+kk]) * i2(f[c], f[c+kk])
+          - rb * i2(w[c   +o], w[c   ]) * i2(f[c-kk], f[c]) ) / rc * dz;
+}
+template<class TF>
+MHH_HD TF advec2_s(const TF* __restrict__ s, const TF* __restrict__ u, const TF* __restrict__ v, const TF* __restrict__ w,
+                   int c, int jj, int kk, TF dxi, TF dyi, TF rt, TF rb, TF rc, TF dz)
+{
+    return
+        - ( u[c+1]  * i2(s[c], s[c+1])  - u[c] * i2(s[c-1],  s[c]) ) * dxi
+        - ( v[c+jj] * i2(s[c], s[c+jj]) - v[c] * i2(s[c-jj], s[c]) ) * dyi
+        - ( rt * w[c+kk] * i2(s[c], s[c+kk]) - rb * w[c] * i2(s[c-kk], s[c]) ) / rc * dz;
+}
+
+// =======================================================================================================
+// advec_2i5 (src/advec_2i5.cxx:151-728)
+// Vertical order table: order of the interpolation on a face. 0 = wall (no flux), 2 = 2nd (no upwind term),
+// 4 = 4th centred + 3rd upwind, 6 = 6th centred + 5th upwind. For u,v,scalars `kf` is the bottom face of cell
+// kf; for w it is the cell centre (the w equation's "faces").
+// =======================================================================================================
+MHH_HD int order_face_c(int kf, int kstart, int kend)
+{
+    if (kf <= kstart || kf >= kend) return 0;
+    if (kf == kstart+1 || kf == kend-1) return 2;
+    if (kf == kstart+2 || kf == kend-2) return 4;
+    return 6;
+}
+MHH_HD int order_face_w(int kc, int kstart, int kend)
+{
+    if (kc == kstart || kc == kend-1) return 2;
+    if (kc == kstart+1 || kc == kend-2) return 4;
+    return 6;
+}
+// interpolants on the face between f[c-s] and f[c]
+template<class TF> MHH_HD TF face_cen(const TF* __restrict__ f, int c, int s, int order)
+{
+    if (order == 2) return i2(f[c-s], f[c]);
+    if (order == 4) return i4ws(f[c-2*s], f[c-s], f[c], f[c+s]);
+    return i6(f[c-3*s], f[c-2*s], f[c-s], f[c], f[c+s], f[c+2*s]);
+}
+template<class TF> MHH_HD TF face_upw(const TF* __restrict__ f, int c, int s, int order)
+{
+    if (order == 4) return i3ws(f[c-2*s], f[c-s], f[c], f[c+s]);
+    return i5(f[c-3*s], f[c-2*s], f[c-s], f[c], f[c+s], f[c+2*s]);
+}
+
+// horizontal increment (:181-201, :333-352, :483-503, :612-632); ue/uw/vn/vs = advecting face velocities
+template<class TF>
+MHH_HD TF advec25_hor(const TF* __restrict__ f, int c, int jj, TF ue, TF uw, TF vn, TF vs, TF dxi, TF dyi)
+{
+    const TF fm3 = f[c-3], fm2 = f[c-2], fm1 = f[c-1], f0 = f[c], fp1 = f[c+1], fp2 = f[c+2], fp3 = f[c+3];
+    const TF gm3 = f[c-3*jj], gm2 = f[c-2*jj], gm1 = f[c-jj], gp1 = f[c+jj], gp2 = f[c+2*jj], gp3 = f[c+3*jj];
+    return
+        - ( ue * i6(fm2, fm1, f0, fp1, fp2, fp3) - uw * i6(fm3, fm2, fm1, f0, fp1, fp2) ) * dxi
+        + ( tabs(ue) * i5(fm2, fm1, f0, fp1, fp2, fp3) - tabs(uw) * i5(fm3, fm2, fm1, f0, fp1, fp2) ) * dxi
+        - ( vn * i6(gm2, gm1, f0, gp1, gp2, gp3) - vs * i6(gm3, gm2, gm1, f0, gp1, gp2) ) * dyi
+        + ( tabs(vn) * i5(gm2, gm1, f0, gp1, gp2, gp3) - tabs(vs) * i5(gm3, gm2, gm1, f0, gp1, gp2) ) * dyi;
+}
+// vertical increment (:204-299 etc.) for face orders ot (top) / ob (bottom)
+template<class TF>
+MHH_HD TF advec25_ver(const TF* __restrict__ f, int c, int kk, int ot, int ob, TF wt, TF wb, TF rt, TF rb, TF rc, TF dz)
+{
+    const TF It = ot ? face_cen(f, c+kk, kk, ot) : TF(0);
+    const TF Ib = ob ? face_cen(f, c, kk, ob) : TF(0);
+    TF cen;
+    if (ob == 0)      cen = - ( rt * wt * It ) / rc * dz;
+    else if (ot == 0) cen = - ( -rb * wb * Ib ) / rc * dz;
+    else              cen = - ( rt * wt * It - rb * wb * Ib ) / rc * dz;
+    const bool ut = (ot >= 4), ub = (ob >= 4);
+    if (ut && ub) return cen + ( rt * tabs(wt) * face_upw(f, c+kk, kk, ot) - rb * tabs(wb) * face_upw(f, c, kk, ob) ) / rc * dz;
+    if (ut)       return cen + ( rt * tabs(wt) * face_upw(f, c+kk, kk, ot) ) / rc * dz;
+    if (ub)       return cen - ( rb * tabs(wb) * face_upw(f, c, kk, ob) ) / rc * dz;
+    return cen;
+}
+
+// =======================================================================================================
+// advec_4 (src/advec_4.cxx:88-486): three separate decrements (x, y if dim3, z); returns them through d[3].
+// sd = staggering stride of the advected momentum component (1, jj, kk); is_w selects the w equation, whose
+// vertical advecting velocity is the advected field itself incl. the biased wall forms.
+// =======================================================================================================
+template<class TF>
+MHH_HD void advec4_mom(TF d[3], const TF* __restrict__ f, const TF* __restrict__ u, const TF* __restrict__ v, const TF* __restrict__ w,
+                       int c, int sd, bool is_w, int jj, int kk, bool bot, bool top, TF dxi, TF dyi, TF dz, bool dim3)
+{
+    const TF cg0 = TF(1./24.), cg1 = TF(-27./24.), cg2 = TF(27./24.), cg3 = TF(-1./24.);
+    {
+        TF p[4];
+        for (int m=0; m<4; ++m)
+        {
+            const int b = c + (m-1);
+            p[m] = ci4(u[b-2*sd], u[b-sd], u[b], u[b+sd]) * ci4(f[c+m-3], f[c+m-2], f[c+m-1], f[c+m]);
+        }
+        d[0] = ( cg0*p[0] + cg1*p[1] + cg2*p[2] + cg3*p[3] ) * dxi;
+    }
+    d[1] = TF(0);
+    if (dim3)
+    {
+        TF p[4];
+        for (int m=0; m<4; ++m)
+        {
+            const int b = c + (m-1)*jj;
+            p[m] = ci4(v[b-2*sd], v[b-sd], v[b], v[b+sd]) * ci4(f[c+(m-3)*jj], f[c+(m-2)*jj], f[c+(m-1)*jj], f[c+m*jj]);
+        }
+        d[1] = ( cg0*p[0] + cg1*p[1] + cg2*p[2] + cg3*p[3] ) * dyi;
+    }
+    {
+        TF p[4];
+        for (int m=0; m<4; ++m)
+        {
+            const int b = c + (m-1)*kk;
+            TF fi;
+            if (bot && m==0)      fi = bi4(f[c-2*kk], f[c-kk], f[c], f[c+kk]);
+            else if (top && m==3) fi = ti4(f[c-kk], f[c], f[c+kk], f[c+2*kk]);
+            else                  fi = ci4(f[c+(m-3)*kk], f[c+(m-2)*kk], f[c+(m-1)*kk], f[c+m*kk]);
+            const TF ve = is_w ? fi : ci4(w[b-2*sd], w[b-sd], w[b], w[b+sd]);
+            p[m] = ve * fi;
+        }
+        d[2] = ( cg0*p[0] + cg1*p[1] + cg2*p[2] + cg3*p[3] ) * dz;
+    }
+}
+template<class TF>
+MHH_HD void advec4_s(TF d[3], const TF* __restrict__ s, const TF* __restrict__ u, const TF* __restrict__ v, const TF* __restrict__ w,
+                     int c, int jj, int kk, bool bot, bool top, TF dxi, TF dyi, TF dz, bool dim3)
+{
+    const TF cg0 = TF(1./24.), cg1 = TF(-27./24.), cg2 = TF(27./24.), cg3 = TF(-1./24.);
+    d[0] = ( cg0*(u[c-1] * ci4(s[c-3], s[c-2], s[c-1], s[c  ]))
+           + cg1*(u[c  ] * ci4(s[c-2], s[c-1], s[c  ], s[c+1]))
+           + cg2*(u[c+1] * ci4(s[c-1], s[c  ], s[c+1], s[c+2]))
+           + cg3*(u[c+2] * ci4(s[c  ], s[c+1], s[c+2], s[c+3])) ) * dxi;
+    d[1] = TF(0);
+    if (dim3)
+        d[1] = ( cg0*(v[c-jj  ] * ci4(s[c-3*jj], s[c-2*jj], s[c-jj], s[c]))
+               + cg1*(v[c     ] * ci4(s[c-2*jj], s[c-jj], s[c], s[c+jj]))
+               + cg2*(v[c+jj  ] * ci4(s[c-jj], s[c], s[c+jj], s[c+2*jj]))
+               + cg3*(v[c+2*jj] * ci4(s[c], s[c+jj], s[c+2*jj], s[c+3*jj])) ) * dyi;
+    const TF f0 = bot ? bi4(s[c-2*kk], s[c-kk], s[c], s[c+kk]) : ci4(s[c-3*kk], s[c-2*kk], s[c-kk], s[c]);
+    const TF f3 = top ? ti4(s[c-kk], s[c], s[c+kk], s[c+2*kk]) : ci4(s[c], s[c+kk], s[c+2*kk], s[c+3*kk]);
+    d[2] = ( cg0*(w[c-kk  ] * f0)
+           + cg1*(w[c     ] * ci4(s[c-2*kk], s[c-kk], s[c], s[c+kk]))
+           + cg2*(w[c+kk  ] * ci4(s[c-kk], s[c], s[c+kk], s[c+2*kk]))
+           + cg3*(w[c+2*kk] * f3) ) * dz;
+}
+
+// calc_cfl integrand (advec_2.cxx:51-78, advec_2i5.cxx:60-148, advec_4.cxx:51-86)
+template<class TF>
+MHH_HD TF cfl_cell(int scheme, const TF* __restrict__ u, const TF* __restrict__ v, const TF* __restrict__ w,
+                   int c, int jj, int kk, int k, int kstart, int kend, TF dxi, TF dyi, TF dzi_k)
+{
+    if (scheme == 2)
+        return tabs(i2(u[c], u[c+1]))*dxi + tabs(i2(v[c], v[c+jj]))*dyi + tabs(i2(w[c], w[c+kk]))*dzi_k;
+    if (scheme == 4)
+        return tabs(i4c(u[c-1], u[c], u[c+1], u[c+2]))*dxi + tabs(i4c(v[c-jj], v[c], v[c+jj], v[c+2*jj]))*dyi
+             + tabs(i4c(w[c-kk], w[c], w[c+kk], w[c+2*kk]))*dzi_k;
+    TF wi;
+    if (k == kstart || k == kend-1)        wi = i2(w[c], w[c+kk]);
+    else if (k == kstart+1 || k == kend-2) wi = i4ws(w[c-kk], w[c], w[c+kk], w[c+2*kk]);
+    else                                   wi = i6(w[c-2*kk], w[c-kk], w[c], w[c+kk], w[c+2*kk], w[c+3*kk]);
+    return tabs(i6(u[c-2], u[c-1], u[c], u[c+1], u[c+2], u[c+3]))*dxi
+         + tabs(i6(v[c-2*jj], v[c-jj], v[c], v[c+jj], v[c+2*jj], v[c+3*jj]))*dyi
+         + tabs(wi)*dzi_k;
+}
+
+// =======================================================================================================
+// diff_2 (src/diff_2.cxx:39-86): at += visc * ( ... ) with DOUBLE dxidxi/dyidyi. Returns the new tendency value
+// (the += is evaluated in the promoted type, so the caller must not re-round).
+//   centred fields: gt=dzhi[k+1] gb=dzhi[k] gc=dzi[k];  w: gt=dzi[k] gb=dzi[k-1] gc=dzhi[k]
+// =======================================================================================================
+template<class TF>
+MHH_HD TF diff2_apply(TF t, const TF* __restrict__ a, int c, int jj, int kk, TF visc, double dxidxi, double dyidyi, TF gt, TF gb, TF gc)
+{
+    t += visc * (
+            + ( (a[c+1 ] - a[c]) - (a[c] - a[c-1 ]) ) * dxidxi
+            + ( (a[c+jj] - a[c]) - (a[c] - a[c-jj]) ) * dyidyi
+            + ( (a[c+kk] - a[c]) * gt - (a[c] - a[c-kk]) * gb ) * gc );
+    return t;
+}
+
+// =======================================================================================================
+// diff_4 (src/diff_4.cxx:41-173): three increments. g4[0..3] = inner metric at the four faces, go = outer metric.
+// =======================================================================================================
+template<class TF>
+MHH_HD void diff4_cell(TF d[3], const TF* __restrict__ a, int c, int jj, int kk, bool bot, bool top, TF visc,
+                       TF dxidxi, TF dyidyi, const TF g4[4], TF go, bool dim3)
+{
+    const TF cdg0 = TF(-1460./576.), cdg1 = TF(783./576.), cdg2 = TF(-54./576.), cdg3 = TF(1./576.);
+    const TF cg0 = TF(1./24.), cg1 = TF(-27./24.), cg2 = TF(27./24.), cg3 = TF(-1./24.);
+    d[0] = visc * (cdg3*a[c-3] + cdg2*a[c-2] + cdg1*a[c-1] + cdg0*a[c] + cdg1*a[c+1] + cdg2*a[c+2] + cdg3*a[c+3])*dxidxi;
+    d[1] = TF(0);
+    if (dim3)
+        d[1] = visc * (cdg3*a[c-3*jj] + cdg2*a[c-2*jj] + cdg1*a[c-jj] + cdg0*a[c] + cdg1*a[c+jj] + cdg2*a[c+2*jj] + cdg3*a[c+3*jj])*dyidyi;
+    const TF g0 = bot ? bg4(a[c-2*kk], a[c-kk], a[c], a[c+kk]) : cg4(a[c-3*kk], a[c-2*kk], a[c-kk], a[c]);
+    const TF g3 = top ? tg4(a[c-kk], a[c], a[c+kk], a[c+2*kk]) : cg4(a[c], a[c+kk], a[c+2*kk], a[c+3*kk]);
+    d[2] = visc * ( cg0*g0 * g4[0]
+                  + cg1*cg4(a[c-2*kk], a[c-kk], a[c], a[c+kk]) * g4[1]
+                  + cg2*cg4(a[c-kk], a[c], a[c+kk], a[c+2*kk]) * g4[2]
+                  + cg3*g3 * g4[3] ) * go;
+}
+
+// =======================================================================================================
+// diff_smag2 (src/diff_smag2.cxx)
+// =======================================================================================================
+// calc_strain2 (:47-155); mo = surface model active on this (lowest) level
+template<class TF>
+MHH_HD TF smag_strain2(const TF* __restrict__ u, const TF* __restrict__ v, const TF* __restrict__ w, int c, int jj, int kk,
+                       bool mo, TF ugradbot, TF vgradbot, TF dxi, TF dyi, TF dzi_k, TF dzhi_k, TF dzhi_kp)
+{
+    TF acc = sq((u[c+1]-u[c])*dxi);
+    acc = acc + sq((v[c+jj]-v[c])*dyi);
+    acc = acc + sq((w[c+kk]-w[c])*dzi_k);
+    acc = acc + TF(0.125)*sq((u[c      ]-u[c  -jj])*dyi + (v[c      ]-v[c-1   ])*dxi);
+    acc = acc + TF(0.125)*sq((u[c+1    ]-u[c+1-jj])*dyi + (v[c+1    ]-v[c     ])*dxi);
+    acc = acc + TF(0.125)*sq((u[c  +jj ]-u[c      ])*dyi + (v[c  +jj]-v[c-1+jj])*dxi);
+    acc = acc + TF(0.125)*sq((u[c+1+jj ]-u[c+1    ])*dyi + (v[c+1+jj]-v[c  +jj])*dxi);
+    if (mo)
+    {
+        acc = acc + TF(0.5)*sq(ugradbot);
+        acc = acc + TF(0.125)*sq((w[c      ]-w[c-1   ])*dxi);
+        acc = acc + TF(0.125)*sq((w[c+1    ]-w[c     ])*dxi);
+        acc = acc + TF(0.125)*sq((w[c  +kk ]-w[c-1+kk])*dxi);
+        acc = acc + TF(0.125)*sq((w[c+1+kk ]-w[c  +kk])*dxi);
+        acc = acc + TF(0.5)*sq(vgradbot);
+        acc = acc + TF(0.125)*sq((w[c      ]-w[c-jj   ])*dyi);
+        acc = acc + TF(0.125)*sq((w[c+jj   ]-w[c      ])*dyi);
+        acc = acc + TF(0.125)*sq((w[c   +kk]-w[c-jj+kk])*dyi);
+        acc = acc + TF(0.125)*sq((w[c+jj+kk]-w[c   +kk])*dyi);
+    }
+    else
+    {
+        acc = acc + TF(0.125)*sq((u[c      ]-u[c  -kk])*dzhi_k  + (w[c      ]-w[c-1   ])*dxi);
+        acc = acc + TF(0.125)*sq((u[c+1    ]-u[c+1-kk])*dzhi_k  + (w[c+1    ]-w[c     ])*dxi);
+        acc = acc + TF(0.125)*sq((u[c  +kk ]-u[c     ])*dzhi_kp + (w[c  +kk ]-w[c-1+kk])*dxi);
+        acc = acc + TF(0.125)*sq((u[c+1+kk ]-u[c+1   ])*dzhi_kp + (w[c+1+kk ]-w[c  +kk])*dxi);
+        acc = acc + TF(0.125)*sq((v[c      ]-v[c   -kk])*dzhi_k  + (w[c      ]-w[c-jj   ])*dyi);
+        acc = acc + TF(0.125)*sq((v[c+jj   ]-v[c+jj-kk])*dzhi_k  + (w[c+jj   ]-w[c      ])*dyi);
+        acc = acc + TF(0.125)*sq((v[c   +kk]-v[c      ])*dzhi_kp + (w[c   +kk]-w[c-jj+kk])*dyi);
+        acc = acc + TF(0.125)*sq((v[c+jj+kk]-v[c+jj   ])*dzhi_kp + (w[c+jj+kk]-w[c   +kk])*dyi);
+    }
+    TF s2 = TF(2.)*acc;
+    s2 += 1.e-9;          // Constants::dsmall is a double: promoted add, narrowed on store
+    return s2;
+}
+
+// diff_u / diff_v (:369-571). fb/ft: this level takes the surface flux at the bottom / top instead of the resolved gradient.
+template<class TF>
+MHH_HD TF smag_diff_u(const TF* __restrict__ u, const TF* __restrict__ v, const TF* __restrict__ w, const TF* __restrict__ ev,
+                      int c, int jj, int kk, bool fb, bool ft, TF fluxbot, TF fluxtop, TF visc, TF dxi, TF dyi,
+                      TF rhk, TF rhkp, TF rk, TF dzi_k, TF dzhi_k, TF dzhi_kp)
+{
+    const TF ee = ev[c] + visc;
+    const TF ew = ev[c-1] + visc;
+    const TF en = TF(0.25)*(ev[c-1   ] + ev[c   ] + ev[c-1+jj] + ev[c+jj]) + visc;
+    const TF es = TF(0.25)*(ev[c-1-jj] + ev[c-jj] + ev[c-1   ] + ev[c   ]) + visc;
+    const TF hor = + ( ee*(u[c+1]-u[c  ])*dxi - ew*(u[c  ]-u[c-1])*dxi ) * TF(2.)*dxi
+                   + ( en*((u[c+jj]-u[c   ])*dyi + (v[c+jj]-v[c-1+jj])*dxi)
+                     - es*((u[c   ]-u[c-jj])*dyi + (v[c   ]-v[c-1   ])*dxi) ) * dyi;
+    TF ver;
+    if (fb)
+    {
+        const TF et = TF(0.25)*(ev[c-1] + ev[c] + ev[c-1+kk] + ev[c+kk]) + visc;
+        ver = ( rhkp * et*((u[c+kk]-u[c])*dzhi_kp + (w[c+kk]-w[c-1+kk])*dxi) + rhk * fluxbot ) / rk * dzi_k;
+    }
+    else if (ft)
+    {
+        const TF eb = TF(0.25)*(ev[c-1-kk] + ev[c-kk] + ev[c-1] + ev[c]) + visc;
+        ver = ( - rhkp * fluxtop - rhk * eb*((u[c]-u[c-kk])*dzhi_k + (w[c]-w[c-1])*dxi) ) / rk * dzi_k;
+    }
+    else
+    {
+        const TF et = TF(0.25)*(ev[c-1   ] + ev[c   ] + ev[c-1+kk] + ev[c+kk]) + visc;
+        const TF eb = TF(0.25)*(ev[c-1-kk] + ev[c-kk] + ev[c-1   ] + ev[c   ]) + visc;
+        ver = ( rhkp * et*((u[c+kk]-u[c   ])*dzhi_kp + (w[c+kk]-w[c-1+kk])*dxi)
+              - rhk  * eb*((u[c   ]-u[c-kk])*dzhi_k  + (w[c   ]-w[c-1   ])*dxi) ) / rk * dzi_k;
+    }
+    return hor + ver;
+}
+template<class TF>
+MHH_HD TF smag_diff_v(const TF* __restrict__ u, const TF* __restrict__ v, const TF* __restrict__ w, const TF* __restrict__ ev,
+                      int c, int jj, int kk, bool fb, bool ft, TF fluxbot, TF fluxtop, TF visc, TF dxi, TF dyi,
+                      TF rhk, TF rhkp, TF rk, TF dzi_k, TF dzhi_k, TF dzhi_kp)
+{
+    const TF ee = TF(0.25)*(ev[c  -jj] + ev[c  ] + ev[c+1-jj] + ev[c+1]) + visc;
+    const TF ew = TF(0.25)*(ev[c-1-jj] + ev[c-1] + ev[c  -jj] + ev[c  ]) + visc;
+    const TF en = ev[c] + visc;
+    const TF es = ev[c-jj] + visc;
+    const TF hor = + ( ee*((v[c+1]-v[c  ])*dxi + (u[c+1]-u[c+1-jj])*dyi)
+                     - ew*((v[c  ]-v[c-1])*dxi + (u[c  ]-u[c  -jj])*dyi) ) * dxi
+                   + ( en*(v[c+jj]-v[c   ])*dyi - es*(v[c   ]-v[c-jj])*dyi ) * TF(2.)*dyi;
+    TF ver;
+    if (fb)
+    {
+        const TF et = TF(0.25)*(ev[c-jj] + ev[c] + ev[c+kk-jj] + ev[c+kk]) + visc;
+        ver = ( rhkp * et*((v[c+kk]-v[c])*dzhi_kp + (w[c+kk]-w[c-jj+kk])*dyi) + rhk * fluxbot ) / rk * dzi_k;
+    }
+    else if (ft)
+    {
+        const TF eb = TF(0.25)*(ev[c-kk-jj] + ev[c-kk] + ev[c-jj] + ev[c]) + visc;
+        ver = ( - rhkp * fluxtop - rhk * eb*((v[c]-v[c-kk])*dzhi_k + (w[c]-w[c-jj])*dyi) ) / rk * dzi_k;
+    }
+    else
+    {
+        const TF et = TF(0.25)*(ev[c   -jj] + ev[c   ] + ev[c+kk-jj] + ev[c+kk]) + visc;
+        const TF eb = TF(0.25)*(ev[c-kk-jj] + ev[c-kk] + ev[c   -jj] + ev[c   ]) + visc;
+        ver = ( rhkp * et*((v[c+kk]-v[c   ])*dzhi_kp + (w[c+kk]-w[c-jj+kk])*dyi)
+              - rhk  * eb*((v[c   ]-v[c-kk])*dzhi_k  + (w[c   ]-w[c-jj   ])*dyi) ) / rk * dzi_k;
+    }
+    return hor + ver;
+}
+// diff_w (:573-617): rk=rhoref[k] rkm=rhoref[k-1] rhk=rhorefh[k]
+template<class TF>
+MHH_HD TF smag_diff_w(const TF* __restrict__ u, const TF* __restrict__ v, const TF* __restrict__ w, const TF* __restrict__ ev,
+                      int c, int jj, int kk, TF visc, TF dxi, TF dyi, TF rk, TF rkm, TF rhk, TF dzi_k, TF dzi_km, TF dzhi_k)
+{
+    const TF ee = TF(0.25)*(ev[c   -kk] + ev[c   ] + ev[c+1 -kk] + ev[c+1 ]) + visc;
+    const TF ew = TF(0.25)*(ev[c-1 -kk] + ev[c-1 ] + ev[c   -kk] + ev[c   ]) + visc;
+    const TF en = TF(0.25)*(ev[c   -kk] + ev[c   ] + ev[c+jj-kk] + ev[c+jj]) + visc;
+    const TF es = TF(0.25)*(ev[c-jj-kk] + ev[c-jj] + ev[c   -kk] + ev[c   ]) + visc;
+    const TF et = ev[c] + visc;
+    const TF eb = ev[c-kk] + visc;
+    return
+        + ( ee*((w[c+1]-w[c  ])*dxi + (u[c+1]-u[c+1-kk])*dzhi_k)
+          - ew*((w[c  ]-w[c-1])*dxi + (u[c  ]-u[c  -kk])*dzhi_k) ) * dxi
+        + ( en*((w[c+jj]-w[c   ])*dyi + (v[c+jj]-v[c+jj-kk])*dzhi_k)
+          - es*((w[c   ]-w[c-jj])*dyi + (v[c   ]-v[c   -kk])*dzhi_k) ) * dyi
+        + ( rk  * et*(w[c+kk]-w[c   ])*dzi_k
+          - rkm * eb*(w[c   ]-w[c-kk])*dzi_km ) / rhk * TF(2.)*dzhi_k;
+}
+// diff_c (:619-709)
+template<class TF>
+MHH_HD TF smag_diff_c(const TF* __restrict__ a, const TF* __restrict__ ev, int c, int jj, int kk, bool fb, bool ft,
+                      TF fluxbot, TF fluxtop, TF tPr, TF visc, TF dxidxi, TF dyidyi,
+                      TF rhk, TF rhkp, TF rk, TF dzi_k, TF dzhi_k, TF dzhi_kp)
+{
+    const TF ee = TF(0.5)*(ev[c   ]+ev[c+1 ])/tPr + visc;
+    const TF ew = TF(0.5)*(ev[c-1 ]+ev[c   ])/tPr + visc;
+    const TF en = TF(0.5)*(ev[c   ]+ev[c+jj])/tPr + visc;
+    const TF es = TF(0.5)*(ev[c-jj]+ev[c   ])/tPr + visc;
+    const TF hor = + ( ee*(a[c+1 ]-a[c]) - ew*(a[c]-a[c-1 ]) ) * dxidxi
+                   + ( en*(a[c+jj]-a[c]) - es*(a[c]-a[c-jj]) ) * dyidyi;
+    TF ver;
+    if (fb)
+    {
+        const TF et = TF(0.5)*(ev[c]+ev[c+kk])/tPr + visc;
+        ver = ( rhkp * et*(a[c+kk]-a[c])*dzhi_kp + rhk * fluxbot ) / rk * dzi_k;
+    }
+    else if (ft)
+    {
+        const TF eb = TF(0.5)*(ev[c-kk]+ev[c])/tPr + visc;
+        ver = ( -rhkp * fluxtop - rhk * eb*(a[c]-a[c-kk])*dzhi_k ) / rk * dzi_k;
+    }
+    else
+    {
+        const TF et = TF(0.5)*(ev[c   ]+ev[c+kk])/tPr + visc;
+        const TF eb = TF(0.5)*(ev[c-kk]+ev[c   ])/tPr + visc;
+        ver = ( rhkp * et*(a[c+kk]-a[c   ])*dzhi_kp
+              - rhk  * eb*(a[c   ]-a[c-kk])*dzhi_k ) / rk * dzi_k;
+    }
+    return hor + ver;
+}
+
+// =======================================================================================================
+// pres_2 / pres_4 pointwise pieces
+// =======================================================================================================
+// Pres_2::input integrand (src/pres_2.cxx:185-195)
+template<class TF>
+MHH_HD TF pres2_in(const TF* __restrict__ u, const TF* __restrict__ v, const TF* __restrict__ w,
+                   const TF* __restrict__ ut, const TF* __restrict__ vt, const TF* __restrict__ wt,
+                   int c, int jj, int kk, TF dxi, TF dyi, TF dti, TF rk, TF rhk, TF rhkp, TF dzi_k)
+{
+    return rk * ( (ut[c+1 ] + u[c+1 ] * dti) - (ut[c] + u[c] * dti) ) * dxi
+         + rk * ( (vt[c+jj] + v[c+jj] * dti) - (vt[c] + v[c] * dti) ) * dyi
+         + ( rhkp * (wt[c+kk] + w[c+kk] * dti)
+           - rhk  * (wt[c   ] + w[c   ] * dti) ) * dzi_k;
+}
+// Pres_4::input integrand (src/pres_4.cxx:305-316); wtm/wtp2 etc. read through the pointers (ghosts set by caller)
+template<class TF>
+MHH_HD TF pres4_in(const TF* __restrict__ u, const TF* __restrict__ v, const TF* __restrict__ w,
+                   const TF* __restrict__ ut, const TF* __restrict__ vt, const TF* __restrict__ wt,
+                   int c, int jj, int kk, TF dxi, TF dyi, TF dti, TF dzi4_k, bool dim3)
+{
+    TF p = cg4(ut[c-1] + u[c-1]*dti, ut[c] + u[c]*dti, ut[c+1] + u[c+1]*dti, ut[c+2] + u[c+2]*dti) * dxi;
+    if (dim3)
+        p += cg4(vt[c-jj] + v[c-jj]*dti, vt[c] + v[c]*dti, vt[c+jj] + v[c+jj]*dti, vt[c+2*jj] + v[c+2*jj]*dti) * dyi;
+    p += cg4(wt[c-kk] + w[c-kk]*dti, wt[c] + w[c]*dti, wt[c+kk] + w[c+kk]*dti, wt[c+2*kk] + w[c+2*kk]*dti) * dzi4_k;
+    return p;
+}
+// divergence integrands (src/pres_2.cxx:411-415, src/pres_4.cxx:755-759)
+template<class TF>
+MHH_HD TF div2_cell(const TF* __restrict__ u, const TF* __restrict__ v, const TF* __restrict__ w, int c, int jj, int kk,
+                    TF dxi, TF dyi, TF rk, TF rhk, TF rhkp, TF dzi_k)
+{
+    return rk*((u[c+1]-u[c])*dxi + (v[c+jj]-v[c])*dyi) + (rhkp*w[c+kk]-rhk*w[c])*dzi_k;
+}
+template<class TF>
+MHH_HD TF div4_cell(const TF* __restrict__ u, const TF* __restrict__ v, const TF* __restrict__ w, int c, int jj, int kk,
+                    TF dxi, TF dyi, TF dzi4_k)
+{
+    return cg4(u[c-1], u[c], u[c+1], u[c+2]) * dxi + cg4(v[c-jj], v[c], v[c+jj], v[c+2*jj]) * dyi
+         + cg4(w[c-kk], w[c], w[c+kk], w[c+2*kk]) * dzi4_k;
+}
+
+} // namespace mhh

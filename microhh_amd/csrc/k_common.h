@@ -1,0 +1,96 @@
+// k_common.h -- host-side plumbing shared by the HIP translation units of libmhh_hip.so:
+// error reporting, mhh_grid -> GridDev<TF> narrowing, the generic cell-kernel launcher.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include "../../include/mhh_hip.h"
+#include "cell_ops.h"
+
+#define MHH_API extern "C" __attribute__((visibility("default")))
+
+namespace mhh
+{
+void set_error(const char* fmt, ...);
+
+#define MHH_HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+    mhh::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return MHH_EHIP; } } while (0)
+#define MHH_REQUIRE(cond, msg) do { if (!(cond)) { mhh::set_error("%s: requirement `%s` failed (%s)", __func__, #cond, msg); return MHH_EINVAL; } } while (0)
+#define MHH_LAUNCH_CHECK() MHH_HIP_TRY(hipGetLastError())
+
+inline hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
+
+template<class TF> inline const TF* cp(const void* p) { return static_cast<const TF*>(p); }
+template<class TF> inline TF* mp(void* p) { return static_cast<TF*>(p); }
+
+// Narrow the ABI grid to the kernel-side descriptor, spelling each reciprocal the way the reference's
+// call sites do (see GridDev comments).
+template<class TF>
+inline GridDev<TF> make_grid(const mhh_grid* g)
+{
+    GridDev<TF> d;
+    d.itot = g->itot; d.jtot = g->jtot; d.ktot = g->ktot; d.imax = g->imax; d.jmax = g->jmax; d.kmax = g->kmax;
+    d.igc = g->igc; d.jgc = g->jgc; d.kgc = g->kgc;
+    d.icells = g->icells; d.jcells = g->jcells; d.ijcells = g->ijcells; d.kcells = g->kcells;
+    d.istart = g->istart; d.iend = g->iend; d.jstart = g->jstart; d.jend = g->jend; d.kstart = g->kstart; d.kend = g->kend;
+    d.dim3 = (g->jtot != 1);
+    const TF dx = TF(g->dx), dy = TF(g->dy);
+    d.dx = dx; d.dy = dy; d.zsize = TF(g->zsize);
+    d.dxi_t = TF(1.)/dx;       d.dyi_t = TF(1.)/dy;
+    d.dxi_d = TF(1./dx);       d.dyi_d = TF(1./dy);
+    d.dxidxi_d = TF(1./(dx*dx)); d.dyidyi_d = TF(1./(dy*dy));
+    d.dxidxi_t = TF(1/(dx*dx));  d.dyidyi_t = TF(1/(dy*dy));
+    d.dxidxi_2 = 1/(dx*dx);      d.dyidyi_2 = 1/(dy*dy);
+    d.z = cp<TF>(g->z); d.dz = cp<TF>(g->dz); d.dzi = cp<TF>(g->dzi); d.dzhi = cp<TF>(g->dzhi);
+    d.dzi4 = cp<TF>(g->dzi4); d.dzhi4 = cp<TF>(g->dzhi4);
+    return d;
+}
+
+inline int check_grid(const mhh_grid* g)
+{
+    if (!g) { set_error("null grid"); return MHH_EINVAL; }
+    if (g->dtype != MHH_F64 && g->dtype != MHH_F32) { set_error("grid dtype must be MHH_F64 or MHH_F32"); return MHH_EINVAL; }
+    if (g->icells != g->imax + 2*g->igc || g->jcells != g->jmax + 2*g->jgc || g->kcells != g->kmax + 2*g->kgc ||
+        g->ijcells != g->icells*g->jcells || g->iend - g->istart != g->imax || g->jend - g->jstart != g->jmax ||
+        g->kend - g->kstart != g->kmax || g->istart != g->igc || g->jstart != g->jgc || g->kstart != g->kgc ||
+        g->imax < 1 || g->jmax < 1 || g->kmax < 1)
+    { set_error("inconsistent grid index bundle"); return MHH_EINVAL; }
+    if (g->npx != 1) { set_error("only slab decomposition (npx == 1) is supported"); return MHH_EINVAL; }
+    return MHH_OK;
+}
+
+// ---- generic one-thread-per-cell kernel --------------------------------------------------------------
+// Block = BX x BY threads over (i, j); blockIdx.z walks the k range, so everything that depends on k
+// (metric rows, density, 2i5 face orders, wall branches) is wave-uniform.
+constexpr int BX = 64, BY = 4;
+
+template<class Op>
+__global__ void __launch_bounds__(BX*BY) cell_kernel(const Op op, int i0, int i1, int j0, int j1, int k0, int jj, int kk)
+{
+    const int i = i0 + blockIdx.x*BX + threadIdx.x;
+    const int j = j0 + blockIdx.y*BY + threadIdx.y;
+    const int k = k0 + blockIdx.z;
+    if (i < i1 && j < j1)
+        op(i, j, k, i + j*jj + k*kk);
+}
+
+template<class Op>
+inline int launch_cells(hipStream_t st, const Op& op, int i0, int i1, int j0, int j1, int k0, int k1, int jj, int kk)
+{
+    if (k1 <= k0 || i1 <= i0 || j1 <= j0) return MHH_OK;
+    dim3 block(BX, BY, 1);
+    dim3 grid((i1-i0 + BX-1)/BX, (j1-j0 + BY-1)/BY, k1-k0);
+    hipLaunchKernelGGL(cell_kernel<Op>, grid, block, 0, st, op, i0, i1, j0, j1, k0, jj, kk);
+    MHH_LAUNCH_CHECK();
+    return MHH_OK;
+}
+template<class TF, class Op>
+inline int launch_interior(hipStream_t st, const GridDev<TF>& g, int k0, int k1, const Op& op)
+{
+    return launch_cells(st, op, g.istart, g.iend, g.jstart, g.jend, k0, k1, g.icells, g.ijcells);
+}
+
+#define MHH_DISPATCH(g, CALL) ((g)->dtype == MHH_F64 ? CALL(double) : CALL(float))
+
+} // namespace mhh

@@ -1,0 +1,528 @@
+// k_pres.hip -- Pres_2 / Pres_4: FFT-based Poisson solver on one GPU (gfx950), rocFFT for the horizontal
+// transforms.
+//
+// Data flow (Pres::exec, src/pres_2.cxx:66-94, src/pres_4.cxx:64-140):
+//   input   : cyclic fill of ut (E-W), vt (N-S); divergence -> packed p (imax*jmax*kmax reals, no ghosts)
+//   forward : rocFFT batched 2-D real-to-complex over every k plane -> spec[ktot][jtot][itot/2+1]
+//   solve   : one thread per (kx,ky) column: Thomas (pres_2) / banded LU (pres_4) in k, on re and im at once
+//   backward: rocFFT 2-D complex-to-real (unnormalised)
+//   unpack  : /jtot /itot, write ghosted p incl. vertical ghost rows and the periodic halo in one kernel
+//   output  : ut,vt,wt -= grad p
+// The reference works on FFTW half-complex *real* coefficients; the complex formulation solves the same
+// real tridiagonal system per wave-number pair (the matrix is real and depends only on
+// bmati[kx]+bmatj[ky]), so results agree to rounding of the transform (DESIGN.md "Parity").
+#include <vector>
+#include <rocfft/rocfft.h>
+#include "k_common.h"
+
+using namespace mhh;
+
+#define MHH_FFT_TRY(expr) do { rocfft_status s_ = (expr); if (s_ != rocfft_status_success) { \
+    mhh::set_error("FFT error: %s returned %d (%s:%d)", #expr, (int)s_, __FILE__, __LINE__); return MHH_EFFT; } } while (0)
+
+struct mhh_pres_plan
+{
+    int order = 0, dtype = 0;
+    int itot = 0, jtot = 0, ktot = 0, nxh = 0;
+    size_t esz = 8;
+    // coefficient tables (device), element type = dtype
+    void* bmati = nullptr; void* bmatj = nullptr;
+    void* a = nullptr; void* c = nullptr; void* dz = nullptr; void* rhoref = nullptr;  // pres_2
+    void* m[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};     // pres_4
+    // buffers
+    void* packed = nullptr;      // imax*jmax*kmax reals
+    void* spec = nullptr;        // nxh*jtot*ktot complex
+    void* work = nullptr;        // scratch of the k-sweep: work3d (pres_2) / 7 band arrays + rhs (pres_4)
+    rocfft_plan fwd = nullptr, bwd = nullptr;
+    rocfft_execution_info fwd_info = nullptr, bwd_info = nullptr;
+    void* fwd_wb = nullptr; void* bwd_wb = nullptr;
+    bool fft_setup = false;
+};
+
+static int g_rocfft_users = 0;
+
+template<class TF> struct C2 { TF x, y; };
+
+// ---- host-side coefficient tables (Pres_2::set_values src/pres_2.cxx:125-153; Pres_4::set_values src/pres_4.cxx:179-252)
+template<class TF>
+static void host_bmat(int order, const mhh_grid* g, std::vector<TF>& bi, std::vector<TF>& bj)
+{
+    const int itot = g->itot, jtot = g->jtot;
+    const TF dx = TF(g->dx), dy = TF(g->dy);
+    const TF dxidxi = 1./(dx*dx), dyidyi = 1./(dy*dy);
+    const TF pi = std::acos(-1.);
+    bi.resize(itot); bj.resize(jtot);
+    if (order == 2)
+    {
+        for (int j=0; j<jtot/2+1; ++j) bj[j] = 2. * (std::cos(2.*pi*(TF)j/(TF)jtot)-1.) * dyidyi;
+        for (int i=0; i<itot/2+1; ++i) bi[i] = 2. * (std::cos(2.*pi*(TF)i/(TF)itot)-1.) * dxidxi;
+    }
+    else
+    {
+        for (int j=0; j<jtot/2+1; j++)
+            bj[j] = ( 2.* (1./576.) * std::cos(6.*pi*(double)j/(double)jtot) - 2.* (54./576.) * std::cos(4.*pi*(double)j/(double)jtot)
+                    + 2.* (783./576.) * std::cos(2.*pi*(double)j/(double)jtot) - (1460./576.) ) * dyidyi;
+        for (int i=0; i<itot/2+1; i++)
+            bi[i] = ( 2.* (1./576.) * std::cos(6.*pi*(double)i/(double)itot) - 2.* (54./576.) * std::cos(4.*pi*(double)i/(double)itot)
+                    + 2.* (783./576.) * std::cos(2.*pi*(double)i/(double)itot) - (1460./576.) ) * dxidxi;
+    }
+    for (int j=jtot/2+1; j<jtot; ++j) bj[j] = bj[jtot-j];
+    for (int i=itot/2+1; i<itot; ++i) bi[i] = bi[itot-i];
+}
+
+template<class TF>
+static int upload(void** dst, const std::vector<TF>& v)
+{
+    MHH_HIP_TRY(hipMalloc(dst, v.size()*sizeof(TF)));
+    MHH_HIP_TRY(hipMemcpy(*dst, v.data(), v.size()*sizeof(TF), hipMemcpyHostToDevice));
+    return MHH_OK;
+}
+
+template<class TF>
+static int plan_tables(mhh_pres_plan* P, const mhh_grid* g, const void* hdz, const void* hdzhi, const void* hdzi4, const void* hdzhi4,
+                       const void* hrho, const void* hrhoh)
+{
+    std::vector<TF> bi, bj;
+    host_bmat<TF>(P->order, g, bi, bj);
+    if (int e = upload(&P->bmati, bi)) return e;
+    if (int e = upload(&P->bmatj, bj)) return e;
+    const int kmax = g->kmax, kgc = g->kgc, kstart = g->kstart;
+    if (P->order == 2)
+    {
+        const TF* dz = cp<TF>(hdz); const TF* dzhi = cp<TF>(hdzhi); const TF* rhoh = cp<TF>(hrhoh); const TF* rho = cp<TF>(hrho);
+        std::vector<TF> a(kmax), c(kmax), dzk(kmax), rk(kmax);
+        for (int k=0; k<kmax; ++k)
+        {
+            a[k] = dz[k+kgc] * rhoh[k+kgc  ]*dzhi[k+kgc  ];
+            c[k] = dz[k+kgc] * rhoh[k+kgc+1]*dzhi[k+kgc+1];
+            dzk[k] = dz[k+kgc]; rk[k] = rho[k+kgc];
+        }
+        if (int e = upload(&P->a, a)) return e;
+        if (int e = upload(&P->c, c)) return e;
+        if (int e = upload(&P->dz, dzk)) return e;
+        if (int e = upload(&P->rhoref, rk)) return e;
+    }
+    else
+    {
+        const TF* dzi4 = cp<TF>(hdzi4); const TF* h = cp<TF>(hdzhi4);
+        std::vector<TF> m1(kmax), m2(kmax), m3(kmax), m4(kmax), m5(kmax), m6(kmax), m7(kmax);
+        int k = 0, kc = kstart;
+        m1[k] = 0.;
+        m2[k] = (1./576.) * (               -  27.*h[kc]                            ) * dzi4[kc];
+        m3[k] = (1./576.) * ( -1.*h[kc+1] + 729.*h[kc] +  27.*h[kc+1]               ) * dzi4[kc];
+        m4[k] = (1./576.) * ( 27.*h[kc+1] - 729.*h[kc] - 729.*h[kc+1] -  1.*h[kc+2] ) * dzi4[kc];
+        m5[k] = (1./576.) * (-27.*h[kc+1] +  27.*h[kc] + 729.*h[kc+1] + 27.*h[kc+2] ) * dzi4[kc];
+        m6[k] = (1./576.) * (  1.*h[kc+1]              -  27.*h[kc+1] - 27.*h[kc+2] ) * dzi4[kc];
+        m7[k] = (1./576.) * (                                         +  1.*h[kc+2] ) * dzi4[kc];
+        for (k=1; k<kmax-1; k++)
+        {
+            kc = kstart+k;
+            m1[k] = (1./576.) * (   1.*h[kc-1]                                           ) * dzi4[kc];
+            m2[k] = (1./576.) * ( -27.*h[kc-1] -  27.*h[kc]                              ) * dzi4[kc];
+            m3[k] = (1./576.) * (  27.*h[kc-1] + 729.*h[kc] +  27.*h[kc+1]               ) * dzi4[kc];
+            m4[k] = (1./576.) * (  -1.*h[kc-1] - 729.*h[kc] - 729.*h[kc+1] -  1.*h[kc+2] ) * dzi4[kc];
+            m5[k] = (1./576.) * (              +  27.*h[kc] + 729.*h[kc+1] + 27.*h[kc+2] ) * dzi4[kc];
+            m6[k] = (1./576.) * (                           -  27.*h[kc+1] - 27.*h[kc+2] ) * dzi4[kc];
+            m7[k] = (1./576.) * (                                          +  1.*h[kc+2] ) * dzi4[kc];
+        }
+        k = kmax-1; kc = kstart+k;
+        m1[k] = (1./576.) * (   1.*h[kc-1]                                         ) * dzi4[kc];
+        m2[k] = (1./576.) * ( -27.*h[kc-1] -  27.*h[kc]                +  1.*h[kc] ) * dzi4[kc];
+        m3[k] = (1./576.) * (  27.*h[kc-1] + 729.*h[kc] +  27.*h[kc+1] - 27.*h[kc] ) * dzi4[kc];
+        m4[k] = (1./576.) * (  -1.*h[kc-1] - 729.*h[kc] - 729.*h[kc+1] + 27.*h[kc] ) * dzi4[kc];
+        m5[k] = (1./576.) * (              +  27.*h[kc] + 729.*h[kc+1] -  1.*h[kc] ) * dzi4[kc];
+        m6[k] = (1./576.) * (                           -  27.*h[kc+1]             ) * dzi4[kc];
+        m7[k] = 0.;
+        std::vector<TF>* mm[7] = {&m1, &m2, &m3, &m4, &m5, &m6, &m7};
+        for (int n=0; n<7; ++n) if (int e = upload(&P->m[n], *mm[n])) return e;
+    }
+    return MHH_OK;
+}
+
+static int make_fft(mhh_pres_plan* P, bool forward, rocfft_plan* plan, rocfft_execution_info* info, void** wb)
+{
+    const size_t lengths[2] = {(size_t)P->itot, (size_t)P->jtot};
+    const size_t rstr[2] = {1, (size_t)P->itot};
+    const size_t cstr[2] = {1, (size_t)P->nxh};
+    const size_t rdist = (size_t)P->itot*P->jtot, cdist = (size_t)P->nxh*P->jtot;
+    const size_t off[2] = {0, 0};
+    rocfft_plan_description d = nullptr;
+    MHH_FFT_TRY(rocfft_plan_description_create(&d));
+    const size_t ndim = (P->jtot > 1) ? 2 : 1;
+    if (forward)
+        MHH_FFT_TRY(rocfft_plan_description_set_data_layout(d, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved, off, off, ndim, rstr, rdist, ndim, cstr, cdist));
+    else
+        MHH_FFT_TRY(rocfft_plan_description_set_data_layout(d, rocfft_array_type_hermitian_interleaved, rocfft_array_type_real, off, off, ndim, cstr, cdist, ndim, rstr, rdist));
+    MHH_FFT_TRY(rocfft_plan_create(plan, rocfft_placement_notinplace, forward ? rocfft_transform_type_real_forward : rocfft_transform_type_real_inverse,
+                                   P->dtype == MHH_F64 ? rocfft_precision_double : rocfft_precision_single, ndim, lengths, (size_t)P->ktot, d));
+    MHH_FFT_TRY(rocfft_plan_description_destroy(d));
+    MHH_FFT_TRY(rocfft_execution_info_create(info));
+    size_t wbs = 0;
+    MHH_FFT_TRY(rocfft_plan_get_work_buffer_size(*plan, &wbs));
+    if (wbs)
+    {
+        MHH_HIP_TRY(hipMalloc(wb, wbs));
+        MHH_FFT_TRY(rocfft_execution_info_set_work_buffer(*info, *wb, wbs));
+    }
+    return MHH_OK;
+}
+
+MHH_API void mhh_pres_plan_destroy(mhh_pres_plan* P)
+{
+    if (!P) return;
+    if (P->fwd) rocfft_plan_destroy(P->fwd);
+    if (P->bwd) rocfft_plan_destroy(P->bwd);
+    if (P->fwd_info) rocfft_execution_info_destroy(P->fwd_info);
+    if (P->bwd_info) rocfft_execution_info_destroy(P->bwd_info);
+    void* bufs[] = {P->bmati, P->bmatj, P->a, P->c, P->dz, P->rhoref, P->packed, P->spec, P->work, P->fwd_wb, P->bwd_wb,
+                    P->m[0], P->m[1], P->m[2], P->m[3], P->m[4], P->m[5], P->m[6]};
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    if (P->fft_setup && --g_rocfft_users == 0) rocfft_cleanup();
+    delete P;
+}
+
+MHH_API int mhh_pres_plan_create(const mhh_grid* g, int order, const void* host_dz, const void* host_dzhi, const void* host_dzi4, const void* host_dzhi4,
+                                 const void* host_rhoref, const void* host_rhorefh, mhh_pres_plan** out)
+{
+    if (int e = check_grid(g)) return e;
+    MHH_REQUIRE(out != nullptr, "out");
+    MHH_REQUIRE(order == 2 || order == 4, "order must be 2 or 4");
+    MHH_REQUIRE(g->npy == 1 && g->imax == g->itot && g->jmax == g->jtot, "single-GPU plan: use the slab driver for npy > 1");
+    if (order == 2) MHH_REQUIRE(host_dz && host_dzhi && host_rhoref && host_rhorefh && g->kgc >= 1 && g->igc >= 1 && g->jgc >= 1, "pres_2 inputs");
+    else            MHH_REQUIRE(host_dzi4 && host_dzhi4 && g->kgc >= 2 && g->igc >= 2 && g->jgc >= 2 && g->kmax >= 4, "pres_4 inputs");
+    mhh_pres_plan* P = new mhh_pres_plan();
+    P->order = order; P->dtype = g->dtype; P->itot = g->itot; P->jtot = g->jtot; P->ktot = g->ktot; P->nxh = g->itot/2 + 1;
+    P->esz = (g->dtype == MHH_F64) ? 8 : 4;
+    int e = (g->dtype == MHH_F64) ? plan_tables<double>(P, g, host_dz, host_dzhi, host_dzi4, host_dzhi4, host_rhoref, host_rhorefh)
+                                  : plan_tables<float>(P, g, host_dz, host_dzhi, host_dzi4, host_dzhi4, host_rhoref, host_rhorefh);
+    const size_t nreal = (size_t)g->itot*g->jtot*g->ktot, ncol = (size_t)P->nxh*g->jtot;
+    const size_t nwork = (order == 2) ? ncol*g->ktot : ncol*(g->ktot+4)*9;   // pres_4: 7 bands + complex rhs
+    if (!e) { hipError_t h = hipMalloc(&P->packed, nreal*P->esz); if (h != hipSuccess) { set_error("hipMalloc packed: %s", hipGetErrorString(h)); e = MHH_ENOMEM; } }
+    if (!e) { hipError_t h = hipMalloc(&P->spec, ncol*g->ktot*2*P->esz); if (h != hipSuccess) { set_error("hipMalloc spec: %s", hipGetErrorString(h)); e = MHH_ENOMEM; } }
+    if (!e) { hipError_t h = hipMalloc(&P->work, nwork*P->esz); if (h != hipSuccess) { set_error("hipMalloc work: %s", hipGetErrorString(h)); e = MHH_ENOMEM; } }
+    if (!e)
+    {
+        if (g_rocfft_users++ == 0) rocfft_setup();
+        P->fft_setup = true;
+        e = make_fft(P, true, &P->fwd, &P->fwd_info, &P->fwd_wb);
+        if (!e) e = make_fft(P, false, &P->bwd, &P->bwd_info, &P->bwd_wb);
+    }
+    if (e) { mhh_pres_plan_destroy(P); return e; }
+    *out = P;
+    return MHH_OK;
+}
+
+// =======================================================================================================
+// input (src/pres_2.cxx:156-196, src/pres_4.cxx:256-317)
+// =======================================================================================================
+template<class TF>
+struct PresInOp
+{
+    GridDev<TF> g; int order; TF* __restrict__ p;
+    const TF* __restrict__ u; const TF* __restrict__ v; const TF* __restrict__ w;
+    const TF* __restrict__ ut; const TF* __restrict__ vt; const TF* __restrict__ wt;
+    const TF* __restrict__ rhoref; const TF* __restrict__ rhorefh; TF dti2, dti4;
+    __device__ void operator()(int i, int j, int k, int c) const
+    {
+        const size_t cp_ = (size_t)(i-g.igc) + (size_t)(j-g.jgc)*g.imax + (size_t)(k-g.kgc)*g.imax*g.jmax;
+        if (order == 2) p[cp_] = pres2_in(u, v, w, ut, vt, wt, c, g.icells, g.ijcells, g.dxi_t, g.dyi_t, dti2, rhoref[k], rhorefh[k], rhorefh[k+1], g.dzi[k]);
+        else            p[cp_] = pres4_in(u, v, w, ut, vt, wt, c, g.icells, g.ijcells, g.dxi_d, g.dyi_d, dti4, g.dzi4[k], g.dim3);
+    }
+};
+// wt ghost rows of pres_4 (src/pres_4.cxx:290-303): wt[kstart-1] = -wt[kstart+1], wt[kend+1] = -wt[kend-1] over the interior columns
+template<class TF>
+struct WtGhostOp
+{
+    GridDev<TF> g; TF* __restrict__ wt;
+    __device__ void operator()(int i, int j, int, int) const
+    {
+        const int b = i + j*g.icells + g.kstart*g.ijcells, t = i + j*g.icells + g.kend*g.ijcells;
+        wt[b-g.ijcells] = -wt[b+g.ijcells];
+        wt[t+g.ijcells] = -wt[t-g.ijcells];
+    }
+};
+
+MHH_API int mhh_pres_input(mhh_pres_plan* P, const mhh_grid* g, const mhh_fields* f, double dt, void* p_packed, void* stream)
+{
+    if (int e = check_grid(g)) return e;
+    MHH_REQUIRE(P && f && f->u && f->v && f->w && f->ut && f->vt && f->wt, "null field");
+    MHH_REQUIRE(P->dtype == g->dtype && P->itot == g->itot && P->jtot == g->jtot && P->ktot == g->ktot, "plan/grid mismatch");
+    MHH_REQUIRE(dt > 0., "dt");
+    if (!p_packed) p_packed = P->packed;
+    const int order = P->order;
+    MHH_REQUIRE(order == 4 || (f->rhoref && f->rhorefh), "rhoref");
+    if (int e = mhh_boundary_cyclic(g, f->ut, MHH_EDGE_EW, stream)) return e;
+    if (order == 2 || g->jtot != 1)
+        if (int e = mhh_boundary_cyclic(g, f->vt, MHH_EDGE_NS, stream)) return e;
+    hipStream_t st = as_stream(stream);
+#define CALL(TF) [&]{ GridDev<TF> gd = make_grid<TF>(g); \
+        if (order == 4) { WtGhostOp<TF> wg{gd, mp<TF>(f->wt)}; if (int e = launch_cells(st, wg, g->istart, g->iend, g->jstart, g->jend, 0, 1, g->icells, g->ijcells)) return e; } \
+        PresInOp<TF> op{gd, order, mp<TF>(p_packed), cp<TF>(f->u), cp<TF>(f->v), cp<TF>(f->w), cp<TF>(f->ut), cp<TF>(f->vt), cp<TF>(f->wt), \
+                        cp<TF>(f->rhoref), cp<TF>(f->rhorefh), TF(1.)/TF(dt), TF(1./TF(dt))}; \
+        return launch_interior(st, gd, g->kstart, g->kend, op); }()
+    return MHH_DISPATCH(g, CALL);
+#undef CALL
+}
+
+// =======================================================================================================
+// spectral solve, pres_2: Thomas algorithm per (kx,ky) column (src/pres_2.cxx:289-330 matrix, :202-263 tdma)
+// =======================================================================================================
+template<class TF>
+__global__ void __launch_bounds__(64) tdma_kernel(C2<TF>* __restrict__ p, TF* __restrict__ work3d,
+                                                  const TF* __restrict__ bmati, const TF* __restrict__ bmatj,
+                                                  const TF* __restrict__ a, const TF* __restrict__ c, const TF* __restrict__ dz, const TF* __restrict__ rho,
+                                                  int nxh, int jtot, int kmax)
+{
+    const int kx = blockIdx.x*64 + threadIdx.x, ky = blockIdx.y;
+    if (kx >= nxh) return;
+    const size_t ncol = (size_t)nxh*jtot, col = kx + (size_t)ky*nxh;
+    const TF bm = bmati[kx] + bmatj[ky];
+    const bool mean = (kx == 0 && ky == 0);
+    TF w2; C2<TF> pp;
+    {   // k = 0
+        const TF dz2 = dz[0]*dz[0];
+        TF b = dz2 * rho[0]*bm - (a[0]+c[0]);
+        b += a[0];
+        if (kmax == 1) { if (mean) b -= c[0]; else b += c[0]; }
+        C2<TF> q = p[col];
+        q.x = dz2 * q.x; q.y = dz2 * q.y;
+        w2 = b;
+        q.x /= w2; q.y /= w2;
+        p[col] = q; pp = q;
+    }
+    for (int k=1; k<kmax; ++k)
+    {
+        const size_t e = col + (size_t)k*ncol;
+        const TF dz2 = dz[k]*dz[k];
+        TF b = dz2 * rho[k]*bm - (a[k]+c[k]);
+        if (k == kmax-1) { if (mean) b -= c[k]; else b += c[k]; }
+        C2<TF> q = p[e];
+        q.x = dz2 * q.x; q.y = dz2 * q.y;
+        const TF w3 = c[k-1] / w2;
+        work3d[e] = w3;
+        w2 = b - a[k]*w3;
+        q.x -= a[k]*pp.x; q.y -= a[k]*pp.y;
+        q.x /= w2; q.y /= w2;
+        p[e] = q; pp = q;
+    }
+    for (int k=kmax-2; k>=0; --k)
+    {
+        const size_t e = col + (size_t)k*ncol;
+        const TF w3 = work3d[e+ncol];
+        C2<TF> q = p[e];
+        q.x -= w3*pp.x; q.y -= w3*pp.y;
+        p[e] = q; pp = q;
+    }
+}
+
+// =======================================================================================================
+// spectral solve, pres_4: 7-band LU without pivoting on kmax+4 unknowns per column (src/pres_4.cxx:358-470, hdma :574-730)
+// Scratch layout: band n (0..6) at W[(n*(kmax+4) + k)*ncol + col], rhs (complex) behind the bands.
+// =======================================================================================================
+template<class TF>
+__global__ void __launch_bounds__(64) hdma_kernel(C2<TF>* __restrict__ p, TF* __restrict__ W,
+                                                  const TF* __restrict__ bmati, const TF* __restrict__ bmatj,
+                                                  const TF* __restrict__ M1, const TF* __restrict__ M2, const TF* __restrict__ M3, const TF* __restrict__ M4,
+                                                  const TF* __restrict__ M5, const TF* __restrict__ M6, const TF* __restrict__ M7,
+                                                  int nxh, int jtot, int kmax)
+{
+    const int kx = blockIdx.x*64 + threadIdx.x, ky = blockIdx.y;
+    if (kx >= nxh) return;
+    const size_t ncol = (size_t)nxh*jtot, col = kx + (size_t)ky*nxh;
+    const int n = kmax+4;
+    const TF bm = bmati[kx] + bmatj[ky];
+    const bool mean = (kx == 0 && ky == 0);
+    TF* __restrict__ m1 = W + 0*(size_t)n*ncol + col; TF* __restrict__ m2 = W + 1*(size_t)n*ncol + col;
+    TF* __restrict__ m3 = W + 2*(size_t)n*ncol + col; TF* __restrict__ m4 = W + 3*(size_t)n*ncol + col;
+    TF* __restrict__ m5 = W + 4*(size_t)n*ncol + col; TF* __restrict__ m6 = W + 5*(size_t)n*ncol + col;
+    TF* __restrict__ m7 = W + 6*(size_t)n*ncol + col;
+    C2<TF>* __restrict__ q = reinterpret_cast<C2<TF>*>(W + 7*(size_t)n*ncol) + col;
+#define A(arr, k) arr[(size_t)(k)*ncol]
+    // fill (rows 0,1: bottom bc; 2..kmax+1: interior; kmax+2, kmax+3: top bc)
+    A(m1,0)=0; A(m2,0)=0; A(m3,0)=0; A(m4,0)=1; A(m5,0)=0;  A(m6,0)=0; A(m7,0)=-1; A(q,0) = C2<TF>{0,0};
+    A(m1,1)=0; A(m2,1)=0; A(m3,1)=0; A(m4,1)=1; A(m5,1)=-1; A(m6,1)=0; A(m7,1)=0;  A(q,1) = C2<TF>{0,0};
+    for (int k=0; k<kmax; ++k)
+    {
+        A(m1,k+2)=M1[k]; A(m2,k+2)=M2[k]; A(m3,k+2)=M3[k]; A(m4,k+2)=M4[k] + bmati[kx] + bmatj[ky];
+        A(m5,k+2)=M5[k]; A(m6,k+2)=M6[k]; A(m7,k+2)=M7[k];
+        A(q,k+2) = p[col + (size_t)k*ncol];
+    }
+    (void)bm;
+    const int t = kmax+2;
+    if (mean) { A(m1,t)=TF(0.);    A(m2,t)=TF(-1/3.); A(m3,t)=TF(2.);  A(m4,t)=TF(1.);
+                A(m1,t+1)=TF(-2.); A(m2,t+1)=TF(9.);  A(m3,t+1)=TF(0.); A(m4,t+1)=TF(1.); }
+    else      { A(m1,t)=TF(0.);    A(m2,t)=TF(0.);    A(m3,t)=TF(-1.); A(m4,t)=TF(1.);
+                A(m1,t+1)=TF(-1.); A(m2,t+1)=TF(0.);  A(m3,t+1)=TF(0.); A(m4,t+1)=TF(1.); }
+    A(m5,t)=0; A(m6,t)=0; A(m7,t)=0; A(q,t) = C2<TF>{0,0};
+    A(m5,t+1)=0; A(m6,t+1)=0; A(m7,t+1)=0; A(q,t+1) = C2<TF>{0,0};
+    // LU
+    int k = 0;
+    A(m1,k)=1; A(m2,k)=1; A(m3,k)=TF(1.)/A(m4,k); A(m4,k)=1; A(m5,k)=A(m5,k)*A(m3,k); A(m6,k)=A(m6,k)*A(m3,k); A(m7,k)=A(m7,k)*A(m3,k);
+    k = 1;
+    A(m1,k)=1; A(m2,k)=1; A(m3,k)=A(m3,k)/A(m4,k-1);
+    A(m4,k)=A(m4,k)-A(m3,k)*A(m5,k-1); A(m5,k)=A(m5,k)-A(m3,k)*A(m6,k-1); A(m6,k)=A(m6,k)-A(m3,k)*A(m7,k-1);
+    k = 2;
+    A(m1,k)=1; A(m2,k)=A(m2,k)/A(m4,k-2);
+    A(m3,k)=( A(m3,k) - A(m2,k)*A(m5,k-2) ) / A(m4,k-1);
+    A(m4,k)=A(m4,k) - A(m3,k)*A(m5,k-1) - A(m2,k)*A(m6,k-2);
+    A(m5,k)=A(m5,k) - A(m3,k)*A(m6,k-1) - A(m2,k)*A(m7,k-2);
+    A(m6,k)=A(m6,k) - A(m3,k)*A(m7,k-1);
+    for (k=3; k<kmax+4; ++k)
+    {
+        if (k == kmax+2) A(m7,kmax+1) = TF(1.);
+        A(m1,k)=( A(m1,k) ) / A(m4,k-3);
+        A(m2,k)=( A(m2,k) - A(m1,k)*A(m5,k-3) ) / A(m4,k-2);
+        A(m3,k)=( A(m3,k) - A(m2,k)*A(m5,k-2) - A(m1,k)*A(m6,k-3) ) / A(m4,k-1);
+        A(m4,k)=  A(m4,k) - A(m3,k)*A(m5,k-1) - A(m2,k)*A(m6,k-2) - A(m1,k)*A(m7,k-3);
+        if (k < kmax+3) A(m5,k)= A(m5,k) - A(m3,k)*A(m6,k-1) - A(m2,k)*A(m7,k-2);
+        if (k < kmax+2) A(m6,k)= A(m6,k) - A(m3,k)*A(m7,k-1);
+        if (k == kmax+2) { A(m6,k)=TF(1.); A(m7,k)=TF(1.); }
+        if (k == kmax+3) { A(m5,k)=TF(1.); A(m6,k)=TF(1.); A(m7,k)=TF(1.); }
+    }
+    // L y = q
+    { C2<TF> q0 = A(q,0), q1 = A(q,1), q2 = A(q,2);
+      q0.x = q0.x*A(m3,0); q0.y = q0.y*A(m3,0);
+      q1.x = q1.x - q0.x*A(m3,1); q1.y = q1.y - q0.y*A(m3,1);
+      q2.x = q2.x - q1.x*A(m3,2) - q0.x*A(m2,2); q2.y = q2.y - q1.y*A(m3,2) - q0.y*A(m2,2);
+      A(q,0) = q0; A(q,1) = q1; A(q,2) = q2; }
+    for (k=3; k<kmax+4; ++k)
+    {
+        const C2<TF> a1 = A(q,k-1), a2 = A(q,k-2), a3 = A(q,k-3); C2<TF> v = A(q,k);
+        v.x = v.x - a1.x*A(m3,k) - a2.x*A(m2,k) - a3.x*A(m1,k);
+        v.y = v.y - a1.y*A(m3,k) - a2.y*A(m2,k) - a3.y*A(m1,k);
+        A(q,k) = v;
+    }
+    // U x = y
+    k = kmax+3;
+    { C2<TF> v0 = A(q,k), v1 = A(q,k-1), v2 = A(q,k-2);
+      v0.x = v0.x / A(m4,k); v0.y = v0.y / A(m4,k);
+      v1.x = ( v1.x - v0.x*A(m5,k-1) ) / A(m4,k-1); v1.y = ( v1.y - v0.y*A(m5,k-1) ) / A(m4,k-1);
+      v2.x = ( v2.x - v1.x*A(m5,k-2) - v0.x*A(m6,k-2) ) / A(m4,k-2); v2.y = ( v2.y - v1.y*A(m5,k-2) - v0.y*A(m6,k-2) ) / A(m4,k-2);
+      A(q,k) = v0; A(q,k-1) = v1; A(q,k-2) = v2; }
+    for (k=kmax; k>=0; --k)
+    {
+        const C2<TF> b1 = A(q,k+1), b2 = A(q,k+2), b3 = A(q,k+3); C2<TF> v = A(q,k);
+        v.x = ( v.x - b1.x*A(m5,k) - b2.x*A(m6,k) - b3.x*A(m7,k) ) / A(m4,k);
+        v.y = ( v.y - b1.y*A(m5,k) - b2.y*A(m6,k) - b3.y*A(m7,k) ) / A(m4,k);
+        A(q,k) = v;
+    }
+    for (k=0; k<kmax; ++k) p[col + (size_t)k*ncol] = A(q,k+2);
+#undef A
+}
+
+// =======================================================================================================
+// unpack (src/pres_2.cxx:333-362, src/pres_4.cxx:481-528): normalise, ghosted layout, vertical ghost rows,
+// periodic halo -- one kernel over icells x jcells x (kmax + vertical ghosts), reading with wrapped indices.
+// =======================================================================================================
+template<class TF>
+__global__ void __launch_bounds__(256) unpack_kernel(TF* __restrict__ p, const TF* __restrict__ packed, int order,
+                                                     int itot, int jtot, int kmax, int igc, int jgc, int kgc, int icells, int jcells)
+{
+    const int i = blockIdx.x*256 + threadIdx.x;
+    const int j = blockIdx.y;
+    const int kz = blockIdx.z;                 // 0 .. kmax-1 + nghost rows
+    if (i >= icells) return;
+    // destination level and source level
+    int kd, ks;
+    if (kz < kmax) { kd = kz + kgc; ks = kz; }
+    else if (order == 2) { kd = kgc - 1; ks = 0; }                        // p[kstart-1] = p[kstart]
+    else
+    {
+        const int gidx = kz - kmax;                                         // 0..3
+        if (gidx == 0)      { kd = kgc - 1;      ks = 0; }                 // p[kstart-1] = p[kstart]
+        else if (gidx == 1) { kd = kgc - 2;      ks = 1; }                 // p[kstart-2] = p[kstart+1]
+        else if (gidx == 2) { kd = kgc + kmax;   ks = kmax-1; }            // p[kend]   = p[kend-1]
+        else                { kd = kgc + kmax+1; ks = kmax-2; }            // p[kend+1] = p[kend-2]
+    }
+    int is = (i - igc) % itot; if (is < 0) is += itot;
+    int js = (j - jgc) % jtot; if (js < 0) js += jtot;
+    const TF val = packed[(size_t)is + (size_t)js*itot + (size_t)ks*itot*jtot] / jtot / itot;
+    p[(size_t)i + (size_t)j*icells + (size_t)kd*icells*jcells] = val;
+}
+
+MHH_API int mhh_pres_solve(mhh_pres_plan* P, const mhh_grid* g, const mhh_fields* f, void* p_packed, void* stream)
+{
+    if (int e = check_grid(g)) return e;
+    MHH_REQUIRE(P && f && f->p, "null field");
+    MHH_REQUIRE(P->dtype == g->dtype && P->itot == g->itot && P->jtot == g->jtot && P->ktot == g->ktot, "plan/grid mismatch");
+    if (!p_packed) p_packed = P->packed;
+    hipStream_t st = as_stream(stream);
+    MHH_FFT_TRY(rocfft_execution_info_set_stream(P->fwd_info, st));
+    MHH_FFT_TRY(rocfft_execution_info_set_stream(P->bwd_info, st));
+    void* in[1] = {p_packed}; void* out[1] = {P->spec};
+    MHH_FFT_TRY(rocfft_execute(P->fwd, in, out, P->fwd_info));
+    dim3 grid((P->nxh + 63)/64, P->jtot);
+    if (P->order == 2)
+    {
+        if (g->dtype == MHH_F64)
+            hipLaunchKernelGGL(tdma_kernel<double>, grid, dim3(64), 0, st, (C2<double>*)P->spec, (double*)P->work, cp<double>(P->bmati), cp<double>(P->bmatj),
+                               cp<double>(P->a), cp<double>(P->c), cp<double>(P->dz), cp<double>(P->rhoref), P->nxh, P->jtot, P->ktot);
+        else
+            hipLaunchKernelGGL(tdma_kernel<float>, grid, dim3(64), 0, st, (C2<float>*)P->spec, (float*)P->work, cp<float>(P->bmati), cp<float>(P->bmatj),
+                               cp<float>(P->a), cp<float>(P->c), cp<float>(P->dz), cp<float>(P->rhoref), P->nxh, P->jtot, P->ktot);
+    }
+    else
+    {
+        if (g->dtype == MHH_F64)
+            hipLaunchKernelGGL(hdma_kernel<double>, grid, dim3(64), 0, st, (C2<double>*)P->spec, (double*)P->work, cp<double>(P->bmati), cp<double>(P->bmatj),
+                               cp<double>(P->m[0]), cp<double>(P->m[1]), cp<double>(P->m[2]), cp<double>(P->m[3]), cp<double>(P->m[4]), cp<double>(P->m[5]), cp<double>(P->m[6]),
+                               P->nxh, P->jtot, P->ktot);
+        else
+            hipLaunchKernelGGL(hdma_kernel<float>, grid, dim3(64), 0, st, (C2<float>*)P->spec, (float*)P->work, cp<float>(P->bmati), cp<float>(P->bmatj),
+                               cp<float>(P->m[0]), cp<float>(P->m[1]), cp<float>(P->m[2]), cp<float>(P->m[3]), cp<float>(P->m[4]), cp<float>(P->m[5]), cp<float>(P->m[6]),
+                               P->nxh, P->jtot, P->ktot);
+    }
+    MHH_LAUNCH_CHECK();
+    void* in2[1] = {P->spec}; void* out2[1] = {p_packed};
+    MHH_FFT_TRY(rocfft_execute(P->bwd, in2, out2, P->bwd_info));
+    const int nghost = (P->order == 2) ? 1 : 4;
+    dim3 ug((g->icells + 255)/256, g->jcells, g->kmax + nghost);
+    if (g->dtype == MHH_F64)
+        hipLaunchKernelGGL(unpack_kernel<double>, ug, dim3(256), 0, st, mp<double>(f->p), cp<double>(p_packed), P->order, g->itot, g->jtot, g->kmax, g->igc, g->jgc, g->kgc, g->icells, g->jcells);
+    else
+        hipLaunchKernelGGL(unpack_kernel<float>, ug, dim3(256), 0, st, mp<float>(f->p), cp<float>(p_packed), P->order, g->itot, g->jtot, g->kmax, g->igc, g->jgc, g->kgc, g->icells, g->jcells);
+    MHH_LAUNCH_CHECK();
+    return MHH_OK;
+}
+
+// =======================================================================================================
+// output (src/pres_2.cxx:365-387, src/pres_4.cxx:533-571)
+// =======================================================================================================
+template<class TF>
+struct PresOutOp
+{
+    GridDev<TF> g; int order; TF* __restrict__ ut; TF* __restrict__ vt; TF* __restrict__ wt; const TF* __restrict__ p;
+    __device__ void operator()(int, int, int k, int c) const
+    {
+        const int jj = g.icells, kk = g.ijcells;
+        if (order == 2)
+        {
+            ut[c] -= (p[c] - p[c-1 ]) * g.dxi_t;
+            vt[c] -= (p[c] - p[c-jj]) * g.dyi_t;
+            wt[c] -= (p[c] - p[c-kk]) * g.dzhi[k];
+        }
+        else
+        {
+            ut[c] -= cg4(p[c-2], p[c-1], p[c], p[c+1]) * g.dxi_d;
+            if (g.dim3) vt[c] -= cg4(p[c-2*jj], p[c-jj], p[c], p[c+jj]) * g.dyi_d;
+            if (k > g.kstart) wt[c] -= cg4(p[c-2*kk], p[c-kk], p[c], p[c+kk]) * g.dzhi4[k];
+        }
+    }
+};
+MHH_API int mhh_pres_output(mhh_pres_plan* P, const mhh_grid* g, const mhh_fields* f, void* stream)
+{
+    if (int e = check_grid(g)) return e;
+    MHH_REQUIRE(P && f && f->p && f->ut && f->vt && f->wt, "null field");
+    const int order = P->order;
+#define CALL(TF) [&]{ PresOutOp<TF> op{make_grid<TF>(g), order, mp<TF>(f->ut), mp<TF>(f->vt), mp<TF>(f->wt), cp<TF>(f->p)}; \
+                      return launch_interior(as_stream(stream), op.g, g->kstart, g->kend, op); }()
+    return MHH_DISPATCH(g, CALL);
+#undef CALL
+}
+
+MHH_API int mhh_pres_exec(mhh_pres_plan* P, const mhh_grid* g, const mhh_fields* f, double dt, void* stream)
+{
+    if (int e = mhh_pres_input(P, g, f, dt, nullptr, stream)) return e;
+    if (int e = mhh_pres_solve(P, g, f, nullptr, stream)) return e;
+    return mhh_pres_output(P, g, f, stream);
+}

@@ -1,0 +1,545 @@
+// k_stencil.hip -- one-thread-per-cell HIP kernels of the stencil operators at the reference's kernel
+// granularity (advec_u/v/w/s, diff_c/w, smag2 pieces, boundary_cyclic, calc_N2, rk substep) and their C-ABI
+// entry points. gfx950 only. The fused multi-tendency RHS kernels live in k_rhs.hip.
+#include <cstdarg>
+#include "k_common.h"
+
+namespace mhh
+{
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...)
+{
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+}
+}
+using namespace mhh;
+
+MHH_API const char* mhh_last_error(void) { return mhh::g_err; }
+MHH_API int mhh_version(void) { return 100; }
+
+// =======================================================================================================
+// Boundary_cyclic (src/boundary_cyclic.cxx:370-443; GPU counterpart src/boundary_cyclic.cu:30-127)
+// One thread per ghost cell, i fastest. East-west first over ALL j,k; then north-south over all i incl.
+// the x ghosts, so corners end up right. Several fields per launch via blockIdx.z / nplanes.
+// =======================================================================================================
+constexpr int MAXF = 8;
+template<class TF> struct FieldList { TF* f[MAXF]; };
+
+template<class TF>
+__global__ void __launch_bounds__(256) cyclic_x_kernel(FieldList<TF> fl, int igc, int iend, int istart, int icells, int nrows)
+{
+    // a row = one (j,k) line; each thread copies one west and one east ghost cell
+    const int t = threadIdx.x % 8;                // igc <= 8
+    const int row = blockIdx.x * (256/8) + threadIdx.x / 8;
+    if (t >= igc || row >= nrows) return;
+    TF* __restrict__ a = fl.f[blockIdx.y] + (size_t)row * icells;
+    a[t] = a[iend - igc + t];
+    a[iend + t] = a[istart + t];
+}
+template<class TF>
+__global__ void __launch_bounds__(256) cyclic_y_kernel(FieldList<TF> fl, int jgc, int jend, int jstart, int icells, int ijcells, int kcells)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int k = blockIdx.y;
+    if (i >= icells) return;
+    TF* __restrict__ a = fl.f[blockIdx.z] + (size_t)k * ijcells;
+    for (int j=0; j<jgc; ++j)
+    {
+        a[i + j*icells] = a[i + (jend - jgc + j)*icells];
+        a[i + (jend + j)*icells] = a[i + (jstart + j)*icells];
+    }
+}
+// jtot == 1: replicate the single row over the y ghosts (interior k only, as the reference)
+template<class TF>
+__global__ void __launch_bounds__(256) cyclic_y2d_kernel(FieldList<TF> fl, int jgc, int jend, int jstart, int icells, int ijcells, int kstart)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int k = kstart + blockIdx.y;
+    if (i >= icells) return;
+    TF* __restrict__ a = fl.f[blockIdx.z] + (size_t)k * ijcells;
+    const TF r = a[i + jstart*icells];
+    for (int j=0; j<jgc; ++j) { a[i + j*icells] = r; a[i + (jend + j)*icells] = r; }
+}
+
+template<class TF>
+static int cyclic_launch(const mhh_grid* g, void* const* data, int nf, int edge, int kcells, int kstart, int kend, hipStream_t st)
+{
+    MHH_REQUIRE(nf >= 1 && nf <= MAXF, "1..8 fields per call");
+    MHH_REQUIRE(g->igc <= 8 && g->jgc <= 8, "ghost width <= 8");
+    FieldList<TF> fl;
+    for (int n=0; n<MAXF; ++n) fl.f[n] = mp<TF>(data[n < nf ? n : 0]);
+    for (int n=0; n<nf; ++n) MHH_REQUIRE(data[n] != nullptr, "null field");
+    if (edge == MHH_EDGE_EW || edge == MHH_EDGE_BOTH)
+    {
+        const int nrows = g->jcells * kcells;
+        hipLaunchKernelGGL(cyclic_x_kernel<TF>, dim3((nrows + 31)/32, nf), dim3(256), 0, st, fl, g->igc, g->iend, g->istart, g->icells, nrows);
+        MHH_LAUNCH_CHECK();
+    }
+    if (edge == MHH_EDGE_NS || edge == MHH_EDGE_BOTH)
+    {
+        if (g->jtot > 1)
+            hipLaunchKernelGGL(cyclic_y_kernel<TF>, dim3((g->icells + 255)/256, kcells, nf), dim3(256), 0, st, fl, g->jgc, g->jend, g->jstart, g->icells, g->ijcells, kcells);
+        else if (kend > kstart)
+            hipLaunchKernelGGL(cyclic_y2d_kernel<TF>, dim3((g->icells + 255)/256, kend-kstart, nf), dim3(256), 0, st, fl, g->jgc, g->jend, g->jstart, g->icells, g->ijcells, kstart);
+        MHH_LAUNCH_CHECK();
+    }
+    return MHH_OK;
+}
+
+MHH_API int mhh_boundary_cyclic_n(const mhh_grid* g, void* const* data, int nfields, int edge, void* stream)
+{
+    if (int e = check_grid(g)) return e;
+    MHH_REQUIRE(edge >= 0 && edge <= 2, "edge");
+    if (g->dtype == MHH_F64) return cyclic_launch<double>(g, data, nfields, edge, g->kcells, g->kstart, g->kend, as_stream(stream));
+    return cyclic_launch<float>(g, data, nfields, edge, g->kcells, g->kstart, g->kend, as_stream(stream));
+}
+MHH_API int mhh_boundary_cyclic(const mhh_grid* g, void* data, int edge, void* stream)
+{
+    void* d[1] = {data};
+    return mhh_boundary_cyclic_n(g, d, 1, edge, stream);
+}
+MHH_API int mhh_boundary_cyclic_2d(const mhh_grid* g, void* data, void* stream)
+{
+    if (int e = check_grid(g)) return e;
+    void* d[1] = {data};
+    // one slice: kcells = 1 and the jtot == 1 branch runs on that slice
+    if (g->dtype == MHH_F64) return cyclic_launch<double>(g, d, 1, MHH_EDGE_BOTH, 1, 0, 1, as_stream(stream));
+    return cyclic_launch<float>(g, d, 1, MHH_EDGE_BOTH, 1, 0, 1, as_stream(stream));
+}
+
+// =======================================================================================================
+// Advection, one tendency per launch
+// =======================================================================================================
+template<class TF>
+struct AdvecOp
+{
+    GridDev<TF> g; int scheme; int comp;           // comp 0..2 momentum, 3 scalar
+    TF* __restrict__ t; const TF* __restrict__ f;
+    const TF* __restrict__ u; const TF* __restrict__ v; const TF* __restrict__ w;
+    const TF* __restrict__ rhoref; const TF* __restrict__ rhorefh;
+
+    __device__ void operator()(int, int, int k, int c) const
+    {
+        const int jj = g.icells, kk = g.ijcells;
+        const bool isw = (comp == 2);
+        if (scheme == MHH_ADVEC_4)
+        {
+            const int k0 = isw ? g.kstart+1 : g.kstart;
+            const bool bot = (k == k0), top = (k == g.kend-1);
+            const TF dz = isw ? g.dzhi4[k] : g.dzi4[k];
+            TF d[3];
+            if (comp == 3) advec4_s(d, f, u, v, w, c, jj, kk, bot, top, g.dxi_t, g.dyi_t, dz, g.dim3);
+            else           advec4_mom(d, f, u, v, w, c, comp==0 ? 1 : (comp==1 ? jj : kk), isw, jj, kk, bot, top, g.dxi_t, g.dyi_t, dz, g.dim3);
+            TF x = t[c];
+            x -= d[0];
+            if (g.dim3) x -= d[1];
+            x -= d[2];
+            t[c] = x;
+            return;
+        }
+        const TF rt = isw ? rhoref[k]   : rhorefh[k+1];
+        const TF rb = isw ? rhoref[k-1] : rhorefh[k];
+        const TF rc = isw ? rhorefh[k]  : rhoref[k];
+        const TF dz = isw ? g.dzhi[k]   : g.dzi[k];
+        const int o = comp==0 ? -1 : (comp==1 ? -jj : -kk);
+        if (scheme == MHH_ADVEC_2)
+        {
+            if (comp == 3) t[c] += advec2_s(f, u, v, w, c, jj, kk, g.dxi_t, g.dyi_t, rt, rb, rc, dz);
+            else           t[c] += advec2_mom(f, u, v, w, c, o, jj, kk, g.dxi_t, g.dyi_t, rt, rb, rc, dz);
+            return;
+        }
+        // 2i5: horizontal then vertical, two separate accumulations (src/advec_2i5.cxx:187,210)
+        TF ue, uw, vn, vs, wtp, wbt; int ot, ob;
+        if (comp == 3)
+        {
+            ue = u[c+1]; uw = u[c]; vn = v[c+jj]; vs = v[c]; wtp = w[c+kk]; wbt = w[c];
+            ot = order_face_c(k+1, g.kstart, g.kend); ob = order_face_c(k, g.kstart, g.kend);
+        }
+        else
+        {
+            ue = i2(u[c+1+o], u[c+1]);   uw = i2(u[c+o], u[c]);
+            vn = i2(v[c+jj+o], v[c+jj]); vs = i2(v[c+o], v[c]);
+            wtp = i2(w[c+kk+o], w[c+kk]); wbt = i2(w[c+o], w[c]);
+            if (isw) { ot = order_face_w(k, g.kstart, g.kend); ob = order_face_w(k-1, g.kstart, g.kend); }
+            else     { ot = order_face_c(k+1, g.kstart, g.kend); ob = order_face_c(k, g.kstart, g.kend); }
+        }
+        TF x = t[c];
+        x += advec25_hor(f, c, jj, ue, uw, vn, vs, g.dxi_t, g.dyi_t);
+        x += advec25_ver(f, c, kk, ot, ob, wtp, wbt, rt, rb, rc, dz);
+        t[c] = x;
+    }
+};
+
+static int check_advec(const mhh_grid* g, int scheme)
+{
+    if (int e = check_grid(g)) return e;
+    MHH_REQUIRE(scheme == MHH_ADVEC_2 || scheme == MHH_ADVEC_2I5 || scheme == MHH_ADVEC_4, "scheme must be 2, 25 or 4");
+    if (scheme == MHH_ADVEC_2)   MHH_REQUIRE(g->igc >= 1 && g->jgc >= 1 && g->kgc >= 1, "advec_2 needs 1 ghost cell");
+    if (scheme == MHH_ADVEC_2I5) MHH_REQUIRE(g->igc >= 3 && g->jgc >= 3 && g->kgc >= 1 && g->ktot >= 6, "advec_2i5 needs gc(3,3,1), ktot>=6 (src/advec_2i5.cxx:42-45)");
+    if (scheme == MHH_ADVEC_4)   MHH_REQUIRE(g->igc >= 3 && g->jgc >= 3 && g->kgc >= 3 && g->ktot >= 2, "advec_4 needs gc(3,3,3)");
+    return MHH_OK;
+}
+
+template<class TF>
+static int advec_launch(const mhh_grid* g, int scheme, int comp, void* t, const void* f, const void* u, const void* v, const void* w,
+                        const void* r, const void* rh, void* stream)
+{
+    AdvecOp<TF> op{make_grid<TF>(g), scheme, comp, mp<TF>(t), cp<TF>(f), cp<TF>(u), cp<TF>(v), cp<TF>(w), cp<TF>(r), cp<TF>(rh)};
+    return launch_interior(as_stream(stream), op.g, comp == 2 ? g->kstart+1 : g->kstart, g->kend, op);
+}
+static int advec_any(const mhh_grid* g, int scheme, int comp, void* t, const void* f, const void* u, const void* v, const void* w,
+                     const void* r, const void* rh, void* stream)
+{
+    if (int e = check_advec(g, scheme)) return e;
+    MHH_REQUIRE(t && f && u && v && w, "null field");
+    MHH_REQUIRE(scheme == MHH_ADVEC_4 || (r && rh), "rhoref/rhorefh required");
+    if (g->dtype == MHH_F64) return advec_launch<double>(g, scheme, comp, t, f, u, v, w, r, rh, stream);
+    return advec_launch<float>(g, scheme, comp, t, f, u, v, w, r, rh, stream);
+}
+MHH_API int mhh_advec_u(const mhh_grid* g, int scheme, void* ut, const void* u, const void* v, const void* w, const void* r, const void* rh, void* s)
+{ return advec_any(g, scheme, 0, ut, u, u, v, w, r, rh, s); }
+MHH_API int mhh_advec_v(const mhh_grid* g, int scheme, void* vt, const void* u, const void* v, const void* w, const void* r, const void* rh, void* s)
+{ return advec_any(g, scheme, 1, vt, v, u, v, w, r, rh, s); }
+MHH_API int mhh_advec_w(const mhh_grid* g, int scheme, void* wt, const void* u, const void* v, const void* w, const void* r, const void* rh, void* s)
+{ return advec_any(g, scheme, 2, wt, w, u, v, w, r, rh, s); }
+MHH_API int mhh_advec_s(const mhh_grid* g, int scheme, void* st, const void* sc, const void* u, const void* v, const void* w, const void* r, const void* rh, void* s)
+{ return advec_any(g, scheme, 3, st, sc, u, v, w, r, rh, s); }
+
+MHH_API int mhh_advec_exec(const mhh_grid* g, int scheme, const mhh_fields* f, void* stream)
+{
+    MHH_REQUIRE(f != nullptr, "fields");
+    MHH_REQUIRE(f->nscalars >= 0 && f->nscalars <= MHH_MAX_SCALARS, "nscalars");
+    if (int e = mhh_advec_u(g, scheme, f->ut, f->u, f->v, f->w, f->rhoref, f->rhorefh, stream)) return e;
+    if (int e = mhh_advec_v(g, scheme, f->vt, f->u, f->v, f->w, f->rhoref, f->rhorefh, stream)) return e;
+    if (int e = mhh_advec_w(g, scheme, f->wt, f->u, f->v, f->w, f->rhoref, f->rhorefh, stream)) return e;
+    for (int n=0; n<f->nscalars; ++n)
+        if (int e = mhh_advec_s(g, scheme, f->st[n], f->s[n], f->u, f->v, f->w, f->rhoref, f->rhorefh, stream)) return e;
+    return MHH_OK;
+}
+
+// =======================================================================================================
+// diff_2 / diff_4
+// =======================================================================================================
+template<class TF>
+struct DiffOp
+{
+    GridDev<TF> g; int order; int is_w; TF visc;
+    TF* __restrict__ t; const TF* __restrict__ a;
+    __device__ void operator()(int, int, int k, int c) const
+    {
+        const int jj = g.icells, kk = g.ijcells;
+        if (order == 2)
+        {
+            const TF gt = is_w ? g.dzi[k]   : g.dzhi[k+1];
+            const TF gb = is_w ? g.dzi[k-1] : g.dzhi[k];
+            const TF gc = is_w ? g.dzhi[k]  : g.dzi[k];
+            t[c] = diff2_apply(t[c], a, c, jj, kk, visc, g.dxidxi_2, g.dyidyi_2, gt, gb, gc);
+            return;
+        }
+        const int k0 = is_w ? g.kstart+1 : g.kstart;
+        const bool bot = (k == k0), top = (k == g.kend-1);
+        const TF* gi = is_w ? g.dzi4 : g.dzhi4;
+        const int s = is_w ? -1 : 0;
+        const TF g4[4] = {gi[k-1+s], gi[k+s], gi[k+1+s], gi[k+2+s]};
+        const TF go = is_w ? g.dzhi4[k] : g.dzi4[k];
+        TF d[3];
+        diff4_cell(d, a, c, jj, kk, bot, top, visc, is_w ? g.dxidxi_t : g.dxidxi_d, is_w ? g.dyidyi_t : g.dyidyi_d, g4, go, g.dim3);
+        TF x = t[c];
+        x += d[0];
+        if (g.dim3) x += d[1];
+        x += d[2];
+        t[c] = x;
+    }
+};
+template<class TF>
+static int diff_launch(const mhh_grid* g, int order, int is_w, void* t, const void* a, double visc, void* stream)
+{
+    DiffOp<TF> op{make_grid<TF>(g), order, is_w, TF(visc), mp<TF>(t), cp<TF>(a)};
+    return launch_interior(as_stream(stream), op.g, is_w ? g->kstart+1 : g->kstart, g->kend, op);
+}
+static int diff_any(const mhh_grid* g, int order, int is_w, void* t, const void* a, double visc, void* stream)
+{
+    if (int e = check_grid(g)) return e;
+    MHH_REQUIRE(order == 2 || order == 4, "order must be 2 or 4");
+    MHH_REQUIRE(t && a, "null field");
+    if (order == 2) MHH_REQUIRE(g->igc >= 1 && g->jgc >= 1 && g->kgc >= 1, "diff_2 needs 1 ghost cell");
+    else            MHH_REQUIRE(g->igc >= 3 && g->jgc >= 3 && g->kgc >= 3, "diff_4 needs gc(3,3,3)");
+    if (g->dtype == MHH_F64) return diff_launch<double>(g, order, is_w, t, a, visc, stream);
+    return diff_launch<float>(g, order, is_w, t, a, visc, stream);
+}
+MHH_API int mhh_diff_c(const mhh_grid* g, int order, void* at, const void* a, double visc, void* stream) { return diff_any(g, order, 0, at, a, visc, stream); }
+MHH_API int mhh_diff_w(const mhh_grid* g, int order, void* wt, const void* w, double visc, void* stream) { return diff_any(g, order, 1, wt, w, visc, stream); }
+
+// =======================================================================================================
+// diff_smag2 pieces
+// =======================================================================================================
+template<class TF>
+struct Strain2Op
+{
+    GridDev<TF> g; int sm; TF* __restrict__ s2;
+    const TF* __restrict__ u; const TF* __restrict__ v; const TF* __restrict__ w;
+    const TF* __restrict__ dudz; const TF* __restrict__ dvdz;
+    __device__ void operator()(int i, int j, int k, int c) const
+    {
+        const bool mo = sm && (k == g.kstart);
+        const int ij = i + j*g.icells;
+        s2[c] = smag_strain2(u, v, w, c, g.icells, g.ijcells, mo, mo ? dudz[ij] : TF(0), mo ? dvdz[ij] : TF(0),
+                             g.dxi_d, g.dyi_d, g.dzi[k], g.dzhi[k], g.dzhi[k+1]);
+    }
+};
+static int check_smag(const mhh_grid* g)
+{
+    if (int e = check_grid(g)) return e;
+    MHH_REQUIRE(g->igc >= 1 && g->jgc >= 1 && g->kgc >= 1, "diff_smag2 needs 1 ghost cell");
+    return MHH_OK;
+}
+MHH_API int mhh_smag2_strain2(const mhh_grid* g, int sm, void* s2, const void* u, const void* v, const void* w, const void* dudz, const void* dvdz, void* stream)
+{
+    if (int e = check_smag(g)) return e;
+    MHH_REQUIRE(s2 && u && v && w, "null field");
+    MHH_REQUIRE(!sm || (dudz && dvdz), "surface model needs dudz, dvdz");
+#define CALL(TF) [&]{ Strain2Op<TF> op{make_grid<TF>(g), sm, mp<TF>(s2), cp<TF>(u), cp<TF>(v), cp<TF>(w), cp<TF>(dudz), cp<TF>(dvdz)}; \
+                      return launch_interior(as_stream(stream), op.g, g->kstart, g->kend, op); }()
+    return MHH_DISPATCH(g, CALL);
+#undef CALL
+}
+
+// calc_evisc (src/diff_smag2.cxx:254-367). mlen0 = cs*pow(dx*dy*dz[k],1/3) per level comes from the host
+// (Diff_smag2::prepare_device computes the same table on the host, src/diff_smag2.cu:521-542) so that the
+// libm call is the CPU's; Mason's n = 2 lets pow(x,2) / pow(y,1/2) be an exact square and a correctly
+// rounded sqrt (see DESIGN.md "Parity").
+template<class TF> __device__ __forceinline__ TF dsqrt(TF x);
+template<> __device__ __forceinline__ double dsqrt<double>(double x) { return __builtin_sqrt(x); }
+template<> __device__ __forceinline__ float  dsqrt<float>(float x)   { return __builtin_sqrtf(x); }
+
+template<class TF>
+struct EviscOp
+{
+    GridDev<TF> g; int sm; TF* __restrict__ ev;
+    const TF* __restrict__ N2; const TF* __restrict__ bgradbot; const TF* __restrict__ z0m; const TF* __restrict__ mlen0;
+    TF tPr;
+    __device__ void operator()(int i, int j, int k, int c) const
+    {
+        const int ij = i + j*g.icells;
+        const TF s2 = ev[c];
+        TF rit = ((sm && k == g.kstart) ? bgradbot[ij] : N2[c]) / s2 / tPr;
+        rit = tmin(rit, TF(1.-1.e-9));
+        TF fac;
+        if (!sm) fac = sq(mlen0[k]);
+        else
+        {
+            const TF kz = TF(0.4)*(g.z[k]+z0m[ij]);
+            const TF mlen = dsqrt(TF(1.)/(TF(1.)/sq(mlen0[k]) + TF(1.)/sq(kz)));
+            fac = sq(mlen);
+        }
+        ev[c] = fac * dsqrt(s2) * dsqrt(TF(1.)-rit);
+    }
+};
+template<class TF>
+struct EviscNeutralOp     // calc_evisc_neutral with surface model (:229-249); Mason n = 1
+{
+    GridDev<TF> g; TF* __restrict__ ev; const TF* __restrict__ z0m; const TF* __restrict__ mlen0;
+    __device__ void operator()(int i, int j, int k, int c) const
+    {
+        const int ij = i + j*g.icells;
+        const TF mlen = TF(1.)/(TF(1.)/mlen0[k] + TF(1.)/(TF(0.4)*(g.z[k]+z0m[ij])));
+        ev[c] = sq(mlen) * dsqrt(ev[c]);
+    }
+};
+template<class TF> __device__ __forceinline__ TF dpow(TF x, TF y);
+template<> __device__ __forceinline__ double dpow<double>(double x, double y) { return pow(x, y); }
+template<> __device__ __forceinline__ float  dpow<float>(float x, float y)    { return powf(x, y); }
+template<class TF> __device__ __forceinline__ TF dexp(TF x);
+template<> __device__ __forceinline__ double dexp<double>(double x) { return exp(x); }
+template<> __device__ __forceinline__ float  dexp<float>(float x)   { return expf(x); }
+
+template<class TF>
+struct EviscNeutralWallOp  // calc_evisc_neutral, resolved walls with van Driest damping (:181-212)
+{
+    GridDev<TF> g; TF* __restrict__ ev; const TF* __restrict__ u; const TF* __restrict__ v; const TF* __restrict__ mlen0; TF visc;
+    __device__ void operator()(int i, int j, int k, int c) const
+    {
+        const int jj = g.icells, kk = g.ijcells;
+        const int cb = i + j*jj + g.kstart*kk, ct = i + j*jj + g.kend*kk;
+        const TF A = TF(26.);
+        const TF utb = dpow( sq( visc*(u[cb] - u[cb-kk])*g.dzhi[g.kstart] ) + sq( visc*(v[cb] - v[cb-kk])*g.dzhi[g.kstart] ), TF(0.25) );
+        const TF utt = dpow( sq( visc*(u[ct] - u[ct-kk])*g.dzhi[g.kend] ) + sq( visc*(v[ct] - v[ct-kk])*g.dzhi[g.kend] ), TF(0.25) );
+        const TF fb = TF(1.) - dexp( -(          g.z[k] *utb) / (A*visc) );
+        const TF ft = TF(1.) - dexp( -((g.zsize-g.z[k])*utt) / (A*visc) );
+        const TF fac = tmin(fb, ft);
+        ev[c] = sq(fac * mlen0[k]) * dsqrt(ev[c]);
+    }
+};
+template<class TF>
+struct MirrorWallOp        // evisc ghost levels in resolved-wall mode (:218-226, :303-311); runs over all icells x jcells
+{
+    GridDev<TF> g; TF* __restrict__ ev;
+    __device__ void operator()(int i, int j, int, int) const
+    {
+        const int b = i + j*g.icells + g.kstart*g.ijcells, t = i + j*g.icells + (g.kend-1)*g.ijcells;
+        ev[b-g.ijcells] = ev[b];
+        ev[t+g.ijcells] = ev[t];
+    }
+};
+
+// host helper: the per-level Smagorinsky length cs*(dx*dy*dz)^(1/3), evaluated with the C library's pow like
+// the reference CPU path (src/diff_smag2.cxx:273,325) -- `g` carries HOST metric pointers here.
+MHH_API int mhh_smag2_mlen0_host(const mhh_grid* g, double cs, void* out)
+{
+    if (int e = check_grid(g)) return e;
+    MHH_REQUIRE(g->dz && out, "null pointer");
+    if (g->dtype == MHH_F64)
+    {
+        const double dx = g->dx, dy = g->dy; const double* dz = cp<double>(g->dz); double* o = mp<double>(out);
+        for (int k=0; k<g->kcells; ++k) o[k] = cs*std::pow(dx*dy*dz[k], double(1./3.));
+    }
+    else
+    {
+        const float dx = (float)g->dx, dy = (float)g->dy, c = (float)cs; const float* dz = cp<float>(g->dz); float* o = mp<float>(out);
+        for (int k=0; k<g->kcells; ++k) o[k] = c*std::pow(dx*dy*dz[k], float(1./3.));
+    }
+    return MHH_OK;
+}
+
+template<class TF>
+static int evisc_finish(const mhh_grid* g, const GridDev<TF>& gd, int sm, void* ev, hipStream_t st)
+{
+    if (!sm)
+    {
+        MirrorWallOp<TF> m{gd, mp<TF>(ev)};
+        if (int e = launch_cells(st, m, 0, g->icells, 0, g->jcells, 0, 1, g->icells, g->ijcells)) return e;
+    }
+    return mhh_boundary_cyclic(g, ev, MHH_EDGE_BOTH, st);
+}
+MHH_API int mhh_smag2_evisc(const mhh_grid* g, int sm, void* ev, const void* N2, const void* bgradbot, const void* z0m,
+                            const void* mlen0, double tPr, void* stream)
+{
+    if (int e = check_smag(g)) return e;
+    MHH_REQUIRE(ev && N2 && mlen0, "null field");
+    MHH_REQUIRE(!sm || (bgradbot && z0m), "surface model needs bgradbot, z0m");
+#define CALL(TF) [&]{ EviscOp<TF> op{make_grid<TF>(g), sm, mp<TF>(ev), cp<TF>(N2), cp<TF>(bgradbot), cp<TF>(z0m), cp<TF>(mlen0), TF(tPr)}; \
+                      if (int e = launch_interior(as_stream(stream), op.g, g->kstart, g->kend, op)) return e; \
+                      return evisc_finish<TF>(g, op.g, sm, ev, as_stream(stream)); }()
+    return MHH_DISPATCH(g, CALL);
+#undef CALL
+}
+MHH_API int mhh_smag2_evisc_neutral(const mhh_grid* g, int sm, void* ev, const void* u, const void* v, const void* z0m,
+                                    const void* mlen0, double visc, void* stream)
+{
+    if (int e = check_smag(g)) return e;
+    MHH_REQUIRE(ev && mlen0, "null field");
+    MHH_REQUIRE(sm ? (z0m != nullptr) : (u && v), "inputs");
+#define CALL(TF) [&]{ GridDev<TF> gd = make_grid<TF>(g); int e; \
+                      if (sm) { EviscNeutralOp<TF> op{gd, mp<TF>(ev), cp<TF>(z0m), cp<TF>(mlen0)}; e = launch_interior(as_stream(stream), gd, g->kstart, g->kend, op); } \
+                      else    { EviscNeutralWallOp<TF> op{gd, mp<TF>(ev), cp<TF>(u), cp<TF>(v), cp<TF>(mlen0), TF(visc)}; e = launch_interior(as_stream(stream), gd, g->kstart, g->kend, op); } \
+                      if (e) return e; return evisc_finish<TF>(g, gd, sm, ev, as_stream(stream)); }()
+    return MHH_DISPATCH(g, CALL);
+#undef CALL
+}
+
+template<class TF>
+struct SmagDiffOp
+{
+    GridDev<TF> g; int comp; int sm;        // comp 0 u, 1 v, 2 w, 3 scalar
+    TF* __restrict__ t; const TF* __restrict__ a;
+    const TF* __restrict__ u; const TF* __restrict__ v; const TF* __restrict__ w; const TF* __restrict__ ev;
+    const TF* __restrict__ fluxbot; const TF* __restrict__ fluxtop;
+    const TF* __restrict__ rhoref; const TF* __restrict__ rhorefh; TF visc, tPr;
+    __device__ void operator()(int i, int j, int k, int c) const
+    {
+        const int jj = g.icells, kk = g.ijcells;
+        if (comp == 2)
+        {
+            t[c] += smag_diff_w(u, v, w, ev, c, jj, kk, visc, g.dxi_d, g.dyi_d, rhoref[k], rhoref[k-1], rhorefh[k], g.dzi[k], g.dzi[k-1], g.dzhi[k]);
+            return;
+        }
+        const bool fb = sm && (k == g.kstart), ft = sm && (k == g.kend-1);
+        const int ij = i + j*jj;
+        const TF flb = fb ? fluxbot[ij] : TF(0), flt = ft ? fluxtop[ij] : TF(0);
+        if (comp == 0)      t[c] += smag_diff_u(u, v, w, ev, c, jj, kk, fb, ft, flb, flt, visc, g.dxi_d, g.dyi_d, rhorefh[k], rhorefh[k+1], rhoref[k], g.dzi[k], g.dzhi[k], g.dzhi[k+1]);
+        else if (comp == 1) t[c] += smag_diff_v(u, v, w, ev, c, jj, kk, fb, ft, flb, flt, visc, g.dxi_d, g.dyi_d, rhorefh[k], rhorefh[k+1], rhoref[k], g.dzi[k], g.dzhi[k], g.dzhi[k+1]);
+        else                t[c] += smag_diff_c(a, ev, c, jj, kk, fb, ft, flb, flt, tPr, visc, g.dxidxi_d, g.dyidyi_d, rhorefh[k], rhorefh[k+1], rhoref[k], g.dzi[k], g.dzhi[k], g.dzhi[k+1]);
+    }
+};
+static int smag_diff_any(const mhh_grid* g, int comp, int sm, void* t, const void* a, const void* u, const void* v, const void* w, const void* ev,
+                         const void* fb, const void* ft, const void* r, const void* rh, double visc, double tPr, void* stream)
+{
+    if (int e = check_smag(g)) return e;
+    MHH_REQUIRE(t && ev && r && rh, "null field");
+    MHH_REQUIRE(comp == 3 ? (a != nullptr) : (u && v && w), "null field");
+    MHH_REQUIRE(comp == 2 || !sm || (fb && ft), "surface model needs fluxbot, fluxtop");
+#define CALL(TF) [&]{ SmagDiffOp<TF> op{make_grid<TF>(g), comp, sm, mp<TF>(t), cp<TF>(a), cp<TF>(u), cp<TF>(v), cp<TF>(w), cp<TF>(ev), cp<TF>(fb), cp<TF>(ft), cp<TF>(r), cp<TF>(rh), TF(visc), TF(tPr)}; \
+                      return launch_interior(as_stream(stream), op.g, comp == 2 ? g->kstart+1 : g->kstart, g->kend, op); }()
+    return MHH_DISPATCH(g, CALL);
+#undef CALL
+}
+MHH_API int mhh_smag2_diff_u(const mhh_grid* g, int sm, void* ut, const void* u, const void* v, const void* w, const void* ev, const void* fb, const void* ft, const void* r, const void* rh, double visc, void* s)
+{ return smag_diff_any(g, 0, sm, ut, nullptr, u, v, w, ev, fb, ft, r, rh, visc, 1., s); }
+MHH_API int mhh_smag2_diff_v(const mhh_grid* g, int sm, void* vt, const void* u, const void* v, const void* w, const void* ev, const void* fb, const void* ft, const void* r, const void* rh, double visc, void* s)
+{ return smag_diff_any(g, 1, sm, vt, nullptr, u, v, w, ev, fb, ft, r, rh, visc, 1., s); }
+MHH_API int mhh_smag2_diff_w(const mhh_grid* g, void* wt, const void* u, const void* v, const void* w, const void* ev, const void* r, const void* rh, double visc, void* s)
+{ return smag_diff_any(g, 2, 0, wt, nullptr, u, v, w, ev, nullptr, nullptr, r, rh, visc, 1., s); }
+MHH_API int mhh_smag2_diff_c(const mhh_grid* g, int sm, void* at, const void* a, const void* ev, const void* fb, const void* ft, const void* r, const void* rh, double tPr, double visc, void* s)
+{ return smag_diff_any(g, 3, sm, at, a, nullptr, nullptr, nullptr, ev, fb, ft, r, rh, visc, tPr, s); }
+
+// Thermo_dry calc_N2 (src/thermo_dry.cxx:66-78)
+template<class TF>
+struct N2Op
+{
+    GridDev<TF> g; TF* __restrict__ N2; const TF* __restrict__ th; const TF* __restrict__ thref; TF grav;
+    __device__ void operator()(int, int, int k, int c) const
+    { N2[c] = grav/thref[k]*TF(0.5)*(th[c+g.ijcells] - th[c-g.ijcells])*g.dzi[k]; }
+};
+MHH_API int mhh_calc_N2(const mhh_grid* g, void* N2, const void* th, const void* thref, double grav, void* stream)
+{
+    if (int e = check_grid(g)) return e;
+    MHH_REQUIRE(N2 && th && thref, "null field");
+#define CALL(TF) [&]{ N2Op<TF> op{make_grid<TF>(g), mp<TF>(N2), cp<TF>(th), cp<TF>(thref), TF(grav)}; \
+                      return launch_interior(as_stream(stream), op.g, g->kstart, g->kend, op); }()
+    return MHH_DISPATCH(g, CALL);
+#undef CALL
+}
+
+// =======================================================================================================
+// Timeloop rk3/rk4 substep (src/timeloop.cxx:250-334): a += cB*dt*at; at = cA_next*at (interior) or 0 (all cells)
+// =======================================================================================================
+template<class TF>
+__global__ void __launch_bounds__(256) rk_kernel(TF* __restrict__ a, TF* __restrict__ at, TF cA, TF cB, TF dt, int reset,
+                                                 int icells, int jcells, int kcells, int istart, int iend, int jstart, int jend, int kstart, int kend)
+{
+    const int i = blockIdx.x*256 + threadIdx.x;
+    const int j = blockIdx.y, k = blockIdx.z;
+    if (i >= icells) return;
+    const size_t c = i + (size_t)j*icells + (size_t)k*icells*jcells;
+    const bool inside = (i >= istart && i < iend && j >= jstart && j < jend && k >= kstart && k < kend);
+    if (inside)
+    {
+        const TF t = at[c];
+        a[c] = a[c] + cB*dt*t;
+        at[c] = reset ? TF(0.) : cA*t;
+    }
+    else if (reset)
+        at[c] = TF(0.);
+}
+MHH_API int mhh_rk_substep(const mhh_grid* g, int rkorder, int substep, double dt, void* a, void* at, void* stream)
+{
+    if (int e = check_grid(g)) return e;
+    MHH_REQUIRE(rkorder == 3 || rkorder == 4, "rkorder 3 or 4");
+    const int ns = (rkorder == 3) ? 3 : 5;
+    MHH_REQUIRE(substep >= 0 && substep < ns && a && at, "substep");
+    static const double A3[] = {0., -5./9., -153./128.};
+    static const double B3[] = {1./3., 15./16., 8./15.};
+    static const double A4[] = {0., -567301805773./1357537059087., -2404267990393./2016746695238., -3550918686646./2091501179385., -1275806237668./842570457699.};
+    static const double B4[] = {1432997174477./9575080441755., 5161836677717./13612068292357., 1720146321549./2090206949498., 3134564353537./4481467310338., 2277821191437./14882151754819.};
+    const int nxt = (substep+1) % ns;
+    const double cA = (rkorder == 3) ? A3[nxt] : A4[nxt], cB = (rkorder == 3) ? B3[substep] : B4[substep];
+    dim3 grid((g->icells+255)/256, g->jcells, g->kcells);
+    if (g->dtype == MHH_F64)
+        hipLaunchKernelGGL(rk_kernel<double>, grid, dim3(256), 0, as_stream(stream), mp<double>(a), mp<double>(at), cA, cB, dt, nxt == 0,
+                           g->icells, g->jcells, g->kcells, g->istart, g->iend, g->jstart, g->jend, g->kstart, g->kend);
+    else
+        hipLaunchKernelGGL(rk_kernel<float>, grid, dim3(256), 0, as_stream(stream), mp<float>(a), mp<float>(at), (float)cA, (float)cB, (float)dt, nxt == 0,
+                           g->icells, g->jcells, g->kcells, g->istart, g->iend, g->jstart, g->jend, g->kstart, g->kend);
+    MHH_LAUNCH_CHECK();
+    return MHH_OK;
+}

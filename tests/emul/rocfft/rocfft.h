@@ -1,0 +1,77 @@
+// tests/emul/rocfft/rocfft.h -- TEST-ONLY stand-in for the slice of rocFFT that k_pres.hip uses, evaluated with a
+// plain O(n^2) DFT on host memory: batched 1-D/2-D real-to-hermitian and hermitian-to-real transforms on
+// contiguous data (the only layouts the library requests). Lets the pressure solver's own kernels
+// (input, column solves, unpack, output) be exercised on the CPU.
+#pragma once
+#include <cstddef>
+#include <cmath>
+#include <complex>
+#include <vector>
+enum rocfft_status { rocfft_status_success = 0, rocfft_status_failure = 1 };
+enum rocfft_result_placement { rocfft_placement_inplace, rocfft_placement_notinplace };
+enum rocfft_transform_type { rocfft_transform_type_complex_forward, rocfft_transform_type_complex_inverse, rocfft_transform_type_real_forward, rocfft_transform_type_real_inverse };
+enum rocfft_precision { rocfft_precision_single, rocfft_precision_double };
+enum rocfft_array_type { rocfft_array_type_complex_interleaved, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved };
+struct rocfft_plan_t { rocfft_transform_type type; rocfft_precision prec; size_t nd, n0, n1, batch; };
+typedef rocfft_plan_t* rocfft_plan;
+typedef int* rocfft_plan_description;
+typedef int* rocfft_execution_info;
+inline rocfft_status rocfft_setup() { return rocfft_status_success; }
+inline rocfft_status rocfft_cleanup() { return rocfft_status_success; }
+inline rocfft_status rocfft_plan_description_create(rocfft_plan_description* d) { *d = new int(0); return rocfft_status_success; }
+inline rocfft_status rocfft_plan_description_destroy(rocfft_plan_description d) { delete d; return rocfft_status_success; }
+inline rocfft_status rocfft_plan_description_set_data_layout(rocfft_plan_description, rocfft_array_type, rocfft_array_type, const size_t*, const size_t*,
+                                                             size_t, const size_t*, size_t, size_t, const size_t*, size_t) { return rocfft_status_success; }
+inline rocfft_status rocfft_plan_create(rocfft_plan* p, rocfft_result_placement, rocfft_transform_type t, rocfft_precision pr, size_t nd, const size_t* len, size_t batch, rocfft_plan_description)
+{ *p = new rocfft_plan_t{t, pr, nd, len[0], nd > 1 ? len[1] : 1, batch}; return rocfft_status_success; }
+inline rocfft_status rocfft_plan_destroy(rocfft_plan p) { delete p; return rocfft_status_success; }
+inline rocfft_status rocfft_execution_info_create(rocfft_execution_info* i) { *i = new int(0); return rocfft_status_success; }
+inline rocfft_status rocfft_execution_info_destroy(rocfft_execution_info i) { delete i; return rocfft_status_success; }
+inline rocfft_status rocfft_plan_get_work_buffer_size(rocfft_plan, size_t* n) { *n = 0; return rocfft_status_success; }
+inline rocfft_status rocfft_execution_info_set_work_buffer(rocfft_execution_info, void*, size_t) { return rocfft_status_success; }
+inline rocfft_status rocfft_execution_info_set_stream(rocfft_execution_info, void*) { return rocfft_status_success; }
+template<class T>
+inline void emul_fft_run(const rocfft_plan_t& P, void* in, void* out)
+{
+    typedef std::complex<double> cd;
+    const size_t n0 = P.n0, n1 = P.n1, nh = n0/2+1;
+    const double pi = std::acos(-1.0);
+    for (size_t b=0; b<P.batch; ++b)
+    {
+        std::vector<cd> full(n0*n1);
+        if (P.type == rocfft_transform_type_real_forward)
+        {
+            const T* r = static_cast<const T*>(in) + b*n0*n1;
+            std::complex<T>* h = static_cast<std::complex<T>*>(out) + b*nh*n1;
+            for (size_t ky=0; ky<n1; ++ky) for (size_t kx=0; kx<nh; ++kx)
+            {
+                cd acc = 0;
+                for (size_t j=0; j<n1; ++j) for (size_t i=0; i<n0; ++i)
+                    acc += (double)r[i + j*n0] * std::polar(1.0, -2*pi*((double)((kx*i) % n0)/n0 + (double)((ky*j) % n1)/n1));
+                h[kx + ky*nh] = std::complex<T>((T)acc.real(), (T)acc.imag());
+            }
+        }
+        else
+        {
+            const std::complex<T>* h = static_cast<const std::complex<T>*>(in) + b*nh*n1;
+            T* r = static_cast<T*>(out) + b*n0*n1;
+            for (size_t ky=0; ky<n1; ++ky) for (size_t kx=0; kx<n0; ++kx)
+            {
+                if (kx < nh) full[kx + ky*n0] = cd(h[kx + ky*nh].real(), h[kx + ky*nh].imag());
+                else { const size_t mx = n0-kx, my = (n1-ky) % n1; full[kx + ky*n0] = std::conj(cd(h[mx + my*nh].real(), h[mx + my*nh].imag())); }
+            }
+            for (size_t j=0; j<n1; ++j) for (size_t i=0; i<n0; ++i)
+            {
+                cd acc = 0;
+                for (size_t ky=0; ky<n1; ++ky) for (size_t kx=0; kx<n0; ++kx)
+                    acc += full[kx + ky*n0] * std::polar(1.0, 2*pi*((double)((kx*i) % n0)/n0 + (double)((ky*j) % n1)/n1));
+                r[i + j*n0] = (T)acc.real();
+            }
+        }
+    }
+}
+inline rocfft_status rocfft_execute(rocfft_plan p, void* in[], void* out[], rocfft_execution_info)
+{
+    if (p->prec == rocfft_precision_double) emul_fft_run<double>(*p, in[0], out[0]); else emul_fft_run<float>(*p, in[0], out[0]);
+    return rocfft_status_success;
+}

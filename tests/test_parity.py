@@ -1,0 +1,320 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle on identical seeded inputs.
+
+Every test runs on two backends (tests/backends.py): ``hip`` = the product on a real MI355X (marked gpu) and
+``emul`` = the same kernel sources executed on the CPU by the test-only HIP stand-in.
+
+Tolerances (fp64 and fp32 alike, stated per test):
+  * stencil operators (advec_*, diff_*, smag2 strain/diff, pres in/out, cfl/dnmul/div maxima, rk, cyclic):
+    BIT-EXACT -- the library is built with -ffp-contract=off and keeps the reference's expression association;
+  * evisc: <= 4 ulp (device sqrt is correctly rounded, glibc pow(x,2)/pow(y,.5) are not guaranteed to be);
+  * van-Driest evisc (pow .25, exp): <= 64 ulp;
+  * pressure solve: |dp| <= 1e-11 max|p| fp64 / 2e-4 fp32 (rocFFT vs the oracle's DFT; complex vs half-complex solve).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import backends as B
+import common as cm
+from common import ptr, dbl
+from microhh_amd import capi
+
+BACKENDS = [pytest.param("emul"), pytest.param("hip", marks=pytest.mark.gpu)]
+DTYPES = [np.float64, np.float32]
+
+
+@pytest.fixture(params=BACKENDS)
+def be(request):
+    return B.get(request.param)
+
+
+def grids2(dtype, small=False):
+    gs = [cm.grid_2nd(16, 12, 10, gc=(3, 3, 1), dtype=dtype), cm.grid_2nd(70, 9, 8, gc=(3, 3, 2), dtype=dtype),
+          cm.grid_2nd(12, 1, 8, gc=(3, 3, 1), dtype=dtype)]
+    return gs[:1] if small else gs
+
+
+def grids4(dtype, small=False):
+    gs = [cm.grid_4th(16, 12, 12, dtype=dtype), cm.grid_4th(66, 5, 8, dtype=dtype), cm.grid_4th(12, 1, 8, dtype=dtype)]
+    return gs[:1] if small else gs
+
+
+def same(a, b):
+    return np.array_equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_boundary_cyclic(be, dtype):
+    O = cm.oracle()
+    for g in grids2(dtype) + grids4(dtype, small=True):
+        c = cm.Case(g)
+        for edge in (cm.EDGE_EW, cm.EDGE_NS, cm.EDGE_BOTH):
+            want = c.u.copy(); O.orc_boundary_cyclic(g.host_struct(), ptr(want), edge)
+            d = be.arr(c.u)
+            B.ok(be, be.lib.mhh_boundary_cyclic(be.grid(g), be.ptr(d), edge, be.stream))
+            assert same(be.host(d), want), (g.shape3, edge)
+        # several fields per launch
+        ds = [be.arr(c.u), be.arr(c.v), be.arr(c.w)]
+        arr = (C.c_void_p * 3)(*[be.ptr(x).value for x in ds])
+        B.ok(be, be.lib.mhh_boundary_cyclic_n(be.grid(g), arr, 3, cm.EDGE_BOTH, be.stream))
+        for x, src in zip(ds, (c.u, c.v, c.w)):
+            want = src.copy(); O.orc_boundary_cyclic(g.host_struct(), ptr(want), cm.EDGE_BOTH)
+            assert same(be.host(x), want)
+        # 2-D slice
+        want = c.dudz.copy(); O.orc_boundary_cyclic_2d(g.host_struct(), ptr(want))
+        d = be.arr(c.dudz)
+        B.ok(be, be.lib.mhh_boundary_cyclic_2d(be.grid(g), be.ptr(d), be.stream))
+        assert same(be.host(d), want)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("scheme", [cm.ADVEC_2, cm.ADVEC_2I5, cm.ADVEC_4])
+def test_advec_kernels_bitexact(be, scheme, dtype):
+    O = cm.oracle()
+    for g in (grids4(dtype) if scheme == cm.ADVEC_4 else grids2(dtype)):
+        c = cm.Case(g); d = B.DevCase(be, c); Gh = g.host_struct()
+        for oname, hname, tname in [("orc_advec_u", "mhh_advec_u", "ut"), ("orc_advec_v", "mhh_advec_v", "vt"), ("orc_advec_w", "mhh_advec_w", "wt")]:
+            want = c.copy_of(tname)
+            getattr(O, oname)(Gh, scheme, ptr(want), ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.rhoref), ptr(c.rhorefh))
+            t = be.arr(getattr(c, tname))
+            B.ok(be, getattr(be.lib, hname)(d.G, scheme, be.ptr(t), be.ptr(d.u), be.ptr(d.v), be.ptr(d.w), be.ptr(d.rhoref), be.ptr(d.rhorefh), be.stream))
+            got = be.host(t)
+            assert same(got, want), (hname, scheme, g.shape3, cm.ulp_diff(got, want))
+        want = c.st[0].copy()
+        O.orc_advec_s(Gh, scheme, ptr(want), ptr(c.s[0]), ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.rhoref), ptr(c.rhorefh))
+        t = be.arr(c.st[0])
+        B.ok(be, be.lib.mhh_advec_s(d.G, scheme, be.ptr(t), be.ptr(d.s[0]), be.ptr(d.u), be.ptr(d.v), be.ptr(d.w), be.ptr(d.rhoref), be.ptr(d.rhorefh), be.stream))
+        assert same(be.host(t), want), ("advec_s", scheme, g.shape3)
+        out = C.c_double(0)
+        B.ok(be, be.lib.mhh_advec_cfl(d.G, scheme, be.ptr(d.u), be.ptr(d.v), be.ptr(d.w), 0.37, be.ptr(d.work), C.byref(out), be.stream))
+        assert out.value == O.orc_advec_cfl(Gh, scheme, ptr(c.u), ptr(c.v), ptr(c.w), dbl(0.37)) and out.value > 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("order", [2, 4])
+def test_diff_kernels_bitexact(be, order, dtype):
+    O = cm.oracle()
+    for g in (grids4(dtype) if order == 4 else grids2(dtype)):
+        c = cm.Case(g); d = B.DevCase(be, c); Gh = g.host_struct()
+        for is_w, src, dsrc, tname in [(0, c.u, d.u, "ut"), (1, c.w, d.w, "wt"), (0, c.s[0], d.s[0], "vt")]:
+            want = c.copy_of(tname)
+            (O.orc_diff_w if is_w else O.orc_diff_c)(Gh, order, ptr(want), ptr(src), dbl(1.3e-2))
+            t = be.arr(getattr(c, tname))
+            B.ok(be, (be.lib.mhh_diff_w if is_w else be.lib.mhh_diff_c)(d.G, order, be.ptr(t), be.ptr(dsrc), 1.3e-2, be.stream))
+            got = be.host(t)
+            assert same(got, want), (order, is_w, g.shape3, cm.ulp_diff(got, want))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("sm", [0, 1])
+def test_smag2_kernels(be, sm, dtype):
+    O = cm.oracle()
+    for g in grids2(dtype)[:2]:
+        c = cm.Case(g); d = B.DevCase(be, c); Gh = g.host_struct()
+        cs, tPr, visc = 0.23, 1./3., 1e-5
+        # strain^2: bit-exact
+        want = np.zeros(g.shape3, dtype=dtype)
+        O.orc_smag2_strain2(Gh, sm, ptr(want), ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.dudz), ptr(c.dvdz))
+        s2 = be.zeros(g.shape3, dtype)
+        B.ok(be, be.lib.mhh_smag2_strain2(d.G, sm, be.ptr(s2), be.ptr(d.u), be.ptr(d.v), be.ptr(d.w), be.ptr(d.dudz), be.ptr(d.dvdz), be.stream))
+        assert same(be.host(s2), want)
+        # evisc from that strain^2: <= 4 ulp, and periodic halo + wall mirror set
+        ml = B.mlen0(be, g, cs)
+        ev_want = want.copy()
+        O.orc_smag2_evisc(Gh, sm, ptr(ev_want), ptr(c.N2), ptr(c.dbdz), ptr(c.z0m), dbl(cs), dbl(tPr))
+        B.ok(be, be.lib.mhh_smag2_evisc(d.G, sm, be.ptr(s2), be.ptr(d.N2), be.ptr(d.dbdz), be.ptr(d.z0m), be.ptr(ml), tPr, be.stream))
+        ev = be.host(s2)
+        k0, k1 = (g.kstart, g.kend) if sm else (g.kstart-1, g.kend+1)
+        assert cm.ulp_diff(ev[k0:k1], ev_want[k0:k1]) <= 4, cm.ulp_diff(ev[k0:k1], ev_want[k0:k1])
+        # neutral variants
+        evn_want = want.copy()
+        O.orc_smag2_evisc_neutral(Gh, sm, ptr(evn_want), ptr(c.u), ptr(c.v), ptr(c.z0m), dbl(cs), dbl(visc))
+        s3 = be.arr(want)
+        B.ok(be, be.lib.mhh_smag2_evisc_neutral(d.G, sm, be.ptr(s3), be.ptr(d.u), be.ptr(d.v), be.ptr(d.z0m), be.ptr(ml), visc, be.stream))
+        evn = be.host(s3)
+        assert cm.ulp_diff(evn[k0:k1], evn_want[k0:k1]) <= (4 if sm else 64)
+        # stress divergence with a given evisc: bit-exact
+        for oname, hname, tname, fb, ft, dfb, dft in [("orc_smag2_diff_u", "mhh_smag2_diff_u", "ut", c.u_fluxbot, c.u_fluxtop, d.u_fluxbot, d.u_fluxtop),
+                                                      ("orc_smag2_diff_v", "mhh_smag2_diff_v", "vt", c.v_fluxbot, c.v_fluxtop, d.v_fluxbot, d.v_fluxtop)]:
+            w_ = c.copy_of(tname)
+            getattr(O, oname)(Gh, sm, ptr(w_), ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.evisc), ptr(fb), ptr(ft), ptr(c.rhoref), ptr(c.rhorefh), dbl(visc))
+            t = be.arr(getattr(c, tname))
+            B.ok(be, getattr(be.lib, hname)(d.G, sm, be.ptr(t), be.ptr(d.u), be.ptr(d.v), be.ptr(d.w), be.ptr(d.evisc), be.ptr(dfb), be.ptr(dft), be.ptr(d.rhoref), be.ptr(d.rhorefh), visc, be.stream))
+            assert same(be.host(t), w_), hname
+        w_ = c.copy_of("wt")
+        O.orc_smag2_diff_w(Gh, ptr(w_), ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.evisc), ptr(c.rhoref), ptr(c.rhorefh), dbl(visc))
+        t = be.arr(c.wt)
+        B.ok(be, be.lib.mhh_smag2_diff_w(d.G, be.ptr(t), be.ptr(d.u), be.ptr(d.v), be.ptr(d.w), be.ptr(d.evisc), be.ptr(d.rhoref), be.ptr(d.rhorefh), visc, be.stream))
+        assert same(be.host(t), w_)
+        w_ = c.st[0].copy()
+        O.orc_smag2_diff_c(Gh, sm, ptr(w_), ptr(c.s[0]), ptr(c.evisc), ptr(c.s_fluxbot), ptr(c.s_fluxtop), ptr(c.rhoref), ptr(c.rhorefh), dbl(tPr), dbl(visc))
+        t = be.arr(c.st[0])
+        B.ok(be, be.lib.mhh_smag2_diff_c(d.G, sm, be.ptr(t), be.ptr(d.s[0]), be.ptr(d.evisc), be.ptr(d.s_fluxbot), be.ptr(d.s_fluxtop), be.ptr(d.rhoref), be.ptr(d.rhorefh), tPr, visc, be.stream))
+        assert same(be.host(t), w_)
+        out = C.c_double(0)
+        for tp in (1./3., 1.7):
+            B.ok(be, be.lib.mhh_smag2_dnmul(d.G, be.ptr(d.evisc), tp, be.ptr(d.work), C.byref(out), be.stream))
+            assert out.value == O.orc_smag2_dnmul(Gh, ptr(c.evisc), dbl(tp))
+        # N2 hook
+        thref = (300. + np.arange(g.kcells)).astype(dtype)
+        w_ = np.zeros(g.shape3, dtype=dtype); O.orc_calc_N2(Gh, ptr(w_), ptr(c.s[0]), ptr(thref), dbl(9.81))
+        n2 = be.zeros(g.shape3, dtype)
+        B.ok(be, be.lib.mhh_calc_N2(d.G, be.ptr(n2), be.ptr(d.s[0]), be.ptr(be.arr(thref)), 9.81, be.stream))
+        assert same(be.host(n2), w_)
+
+
+def _oracle_rhs(c, adv, dif, sm, tPr=1./3., visc=1e-5, svisc=1e-5):
+    """Advec::exec followed by Diff::exec on the oracle; returns the tendencies."""
+    O = cm.oracle(); g = c.grid; Gh = g.host_struct()
+    ut, vt, wt, st = c.ut.copy(), c.vt.copy(), c.wt.copy(), [x.copy() for x in c.st]
+    a = (ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.rhoref), ptr(c.rhorefh))
+    O.orc_advec_u(Gh, adv, ptr(ut), *a); O.orc_advec_v(Gh, adv, ptr(vt), *a); O.orc_advec_w(Gh, adv, ptr(wt), *a)
+    for n in range(len(st)):
+        O.orc_advec_s(Gh, adv, ptr(st[n]), ptr(c.s[n]), *a)
+    if dif in (cm.DIFF_2, cm.DIFF_4):
+        o = 2 if dif == cm.DIFF_2 else 4
+        O.orc_diff_c(Gh, o, ptr(ut), ptr(c.u), dbl(visc)); O.orc_diff_c(Gh, o, ptr(vt), ptr(c.v), dbl(visc)); O.orc_diff_w(Gh, o, ptr(wt), ptr(c.w), dbl(visc))
+        for n in range(len(st)):
+            O.orc_diff_c(Gh, o, ptr(st[n]), ptr(c.s[n]), dbl(svisc))
+    else:
+        O.orc_smag2_diff_u(Gh, sm, ptr(ut), ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.evisc), ptr(c.u_fluxbot), ptr(c.u_fluxtop), ptr(c.rhoref), ptr(c.rhorefh), dbl(visc))
+        O.orc_smag2_diff_v(Gh, sm, ptr(vt), ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.evisc), ptr(c.v_fluxbot), ptr(c.v_fluxtop), ptr(c.rhoref), ptr(c.rhorefh), dbl(visc))
+        O.orc_smag2_diff_w(Gh, ptr(wt), ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.evisc), ptr(c.rhoref), ptr(c.rhorefh), dbl(visc))
+        for n in range(len(st)):
+            O.orc_smag2_diff_c(Gh, sm, ptr(st[n]), ptr(c.s[n]), ptr(c.evisc), ptr(c.s_fluxbot), ptr(c.s_fluxtop), ptr(c.rhoref), ptr(c.rhorefh), dbl(tPr), dbl(svisc))
+    return ut, vt, wt, st
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("adv,dif,sm", [(cm.ADVEC_2, cm.DIFF_2, 0), (cm.ADVEC_2I5, cm.DIFF_SMAG2, 0), (cm.ADVEC_2I5, cm.DIFF_SMAG2, 1), (cm.ADVEC_4, cm.DIFF_4, 0)])
+def test_operator_exec_and_fused_rhs_bitexact(be, adv, dif, sm, dtype):
+    """Advec::exec + Diff::exec (unfused entry points) and the fused mhh_rhs_exec give the oracle's bits."""
+    for g in (grids4(dtype) if adv == cm.ADVEC_4 else grids2(dtype)):
+        if adv == cm.ADVEC_2I5 and g.jtot == 1 and dif == cm.DIFF_SMAG2 and False:
+            continue
+        for nsc in (1, 2):
+            c = cm.Case(g, nscalars=nsc)
+            want = _oracle_rhs(c, adv, dif, sm)
+            p = capi.MhhDiffParams(); p.cs = 0.23; p.tPr = 1./3.; p.surface_model = sm
+            # unfused
+            d = B.DevCase(be, c); f = d.fields()
+            B.ok(be, be.lib.mhh_advec_exec(d.G, adv, C.byref(f), be.stream))
+            B.ok(be, be.lib.mhh_diff_exec(d.G, dif, C.byref(f), C.byref(p), be.stream))
+            got = (be.host(d.ut), be.host(d.vt), be.host(d.wt), [be.host(x) for x in d.st])
+            for a, b, nm in zip(got[:3], want[:3], "uvw"):
+                assert same(a, b), ("unfused", nm, adv, dif, g.shape3, cm.ulp_diff(a, b))
+            for a, b in zip(got[3], want[3]):
+                assert same(a, b), ("unfused s", adv, dif)
+            # fused
+            d = B.DevCase(be, c); f = d.fields()
+            B.ok(be, be.lib.mhh_rhs_exec(d.G, adv, dif, C.byref(f), C.byref(p), be.stream))
+            got = (be.host(d.ut), be.host(d.vt), be.host(d.wt), [be.host(x) for x in d.st])
+            for a, b, nm in zip(got[:3], want[:3], "uvw"):
+                assert same(a, b), ("fused", nm, adv, dif, g.shape3, cm.ulp_diff(a, b))
+            for a, b in zip(got[3], want[3]):
+                assert same(a, b), ("fused s", adv, dif)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("sm,neutral", [(1, 0), (0, 0), (1, 1)])
+def test_exec_viscosity(be, sm, neutral, dtype):
+    """Diff_smag2::exec_viscosity as one pass (strain2 + inline N2 + evisc + cyclic) vs the oracle's three steps."""
+    O = cm.oracle()
+    for g in grids2(dtype)[:2]:
+        c = cm.Case(g, periodic=True); Gh = g.host_struct()
+        cs, tPr, grav = 0.23, 1./3., 9.81
+        thref = np.full(g.kcells, 300., dtype=dtype)
+        want = np.zeros(g.shape3, dtype=dtype)
+        O.orc_smag2_strain2(Gh, sm, ptr(want), ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.dudz), ptr(c.dvdz))
+        if neutral:
+            O.orc_smag2_evisc_neutral(Gh, sm, ptr(want), ptr(c.u), ptr(c.v), ptr(c.z0m), dbl(cs), dbl(1e-5))
+        else:
+            n2 = np.zeros(g.shape3, dtype=dtype); O.orc_calc_N2(Gh, ptr(n2), ptr(c.s[0]), ptr(thref), dbl(grav))
+            O.orc_smag2_evisc(Gh, sm, ptr(want), ptr(n2), ptr(c.dbdz), ptr(c.z0m), dbl(cs), dbl(tPr))
+        d = B.DevCase(be, c); f = d.fields()
+        p = capi.MhhDiffParams(); p.cs = cs; p.tPr = tPr; p.surface_model = sm; p.neutral = neutral
+        p.N2 = None; p.th_for_N2 = 0; dthref = be.arr(thref); p.thref = be.ptr(dthref).value; p.grav = grav
+        ml = B.mlen0(be, g, cs); p.mlen0 = be.ptr(ml).value
+        B.ok(be, be.lib.mhh_diff_exec_viscosity(d.G, cm.DIFF_SMAG2, C.byref(f), C.byref(p), be.stream))
+        ev = be.host(d.evisc)
+        k0, k1 = (g.kstart, g.kend) if sm else (g.kstart-1, g.kend+1)
+        assert cm.ulp_diff(ev[k0:k1], want[k0:k1]) <= 4, cm.ulp_diff(ev[k0:k1], want[k0:k1])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("order", [2, 4])
+def test_pres(be, order, dtype):
+    O = cm.oracle()
+    gl = [cm.grid_2nd(16, 12, 10, gc=(1, 1, 1), dtype=dtype), cm.grid_2nd(12, 10, 8, gc=(3, 3, 1), dtype=dtype), cm.grid_2nd(12, 1, 8, gc=(1, 1, 1), dtype=dtype)] if order == 2 \
+        else [cm.grid_4th(16, 12, 12, dtype=dtype), cm.grid_4th(12, 1, 8, dtype=dtype)]
+    tol = 1e-11 if dtype == np.float64 else 2e-4
+    for g in gl:
+        c = cm.Case(g, rho=("random" if order == 2 else "one"), periodic=True)
+        if order == 4:
+            for m in (1, 2):
+                c.w[g.kstart-m] = -c.w[g.kstart+m]; c.w[g.kend+m] = -c.w[g.kend-m]
+        Gh = g.host_struct(); dt = 0.7
+        d = B.DevCase(be, c); f = d.fields()
+        plan = capi.PLAN()
+        B.ok(be, be.lib.mhh_pres_plan_create(Gh, order, ptr(g.dz), ptr(g.dzhi), ptr(g.dzi4), ptr(g.dzhi4), ptr(c.rhoref), ptr(c.rhorefh), C.byref(plan)))
+        try:
+            # stage 1: input -- bit-exact incl. the ghost-cell side effects on ut, vt (and wt for pres_4)
+            pk_want = np.zeros((g.ktot, g.jtot, g.itot), dtype=dtype)
+            ut, vt, wt = c.ut.copy(), c.vt.copy(), c.wt.copy()
+            O.orc_pres_input(Gh, order, ptr(pk_want), ptr(c.u), ptr(c.v), ptr(c.w), ptr(ut), ptr(vt), ptr(wt), ptr(c.rhoref), ptr(c.rhorefh), dbl(dt))
+            pk = be.zeros((g.ktot, g.jtot, g.itot), dtype)
+            B.ok(be, be.lib.mhh_pres_input(plan, d.G, C.byref(f), dt, be.ptr(pk), be.stream))
+            assert same(be.host(pk), pk_want)
+            assert same(be.host(d.ut), ut) and same(be.host(d.vt), vt) and same(be.host(d.wt), wt)
+            # stage 2: solve
+            p_want = np.zeros(g.shape3, dtype=dtype)
+            pk_tmp = pk_want.copy()
+            O.orc_pres_solve(Gh, order, ptr(p_want), ptr(pk_tmp), ptr(c.rhoref), ptr(c.rhorefh))
+            B.ok(be, be.lib.mhh_pres_solve(plan, d.G, C.byref(f), be.ptr(pk), be.stream))
+            p_got = be.host(d.p)
+            kg = 1 if order == 2 else 2
+            sl = (slice(g.kstart-kg, g.kend + (0 if order == 2 else 2)), slice(None) if g.jtot > 1 else slice(g.jstart, g.jend), slice(None))
+            scale = np.abs(p_want).max()
+            assert np.abs(p_got[sl] - p_want[sl]).max() <= tol*scale, np.abs(p_got[sl] - p_want[sl]).max()/scale
+            # stage 3: output, from the oracle's p so that the stage itself is checked bit-exactly
+            dp = be.arr(p_want); f2 = d.fields(); f2.p = be.ptr(dp).value
+            O.orc_pres_output(Gh, order, ptr(ut), ptr(vt), ptr(wt), ptr(p_want))
+            B.ok(be, be.lib.mhh_pres_output(plan, d.G, C.byref(f2), be.stream))
+            assert same(be.host(d.ut), ut) and same(be.host(d.vt), vt) and same(be.host(d.wt), wt)
+            # whole operator: projection leaves a divergence-free (u/dt + ut)
+            d2 = B.DevCase(be, c); f3 = d2.fields()
+            B.ok(be, be.lib.mhh_pres_exec(plan, d2.G, C.byref(f3), dt, be.stream))
+            B.ok(be, be.lib.mhh_pres_input(plan, d2.G, C.byref(f3), dt, be.ptr(pk), be.stream))
+            assert np.abs(be.host(pk)).max() <= (1e-9 if dtype == np.float64 else 2e-2) * np.abs(pk_want).max()
+            # check_divergence reduction: bit-exact
+            out = C.c_double(0)
+            B.ok(be, be.lib.mhh_pres_check_divergence(d.G, order, C.byref(f), be.ptr(d.work), C.byref(out), be.stream))
+            assert out.value == O.orc_pres_divergence(Gh, order, ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.rhoref), ptr(c.rhorefh))
+        finally:
+            be.lib.mhh_pres_plan_destroy(plan)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_rk_substep_bitexact(be, dtype):
+    O = cm.oracle()
+    g = cm.grid_2nd(16, 12, 10, dtype=dtype)
+    c = cm.Case(g)
+    for order, nsub in ((3, 3), (4, 5)):
+        for sub in range(nsub):
+            a, at = c.u.copy(), c.ut.copy()
+            O.orc_rk_substep(g.host_struct(), order, sub, dbl(0.31), ptr(a), ptr(at))
+            da, dat = be.arr(c.u), be.arr(c.ut)
+            B.ok(be, be.lib.mhh_rk_substep(be.grid(g), order, sub, 0.31, be.ptr(da), be.ptr(dat), be.stream))
+            assert same(be.host(da), a) and same(be.host(dat), at), (order, sub)
+
+
+def test_errors_are_reported(be):
+    g = cm.grid_2nd(16, 12, 10, gc=(1, 1, 1))
+    c = cm.Case(g); d = B.DevCase(be, c)
+    rc = be.lib.mhh_advec_u(d.G, cm.ADVEC_2I5, be.ptr(d.ut), be.ptr(d.u), be.ptr(d.v), be.ptr(d.w), be.ptr(d.rhoref), be.ptr(d.rhorefh), be.stream)
+    assert rc == 1 and b"advec_2i5" in be.lib.mhh_last_error()
+    with pytest.raises(capi.MhhError):
+        B.ok(be, be.lib.mhh_advec_u(d.G, 7, be.ptr(d.ut), be.ptr(d.u), be.ptr(d.v), be.ptr(d.w), be.ptr(d.rhoref), be.ptr(d.rhorefh), be.stream))
+    assert be.lib.mhh_diff_c(d.G, 2, None, be.ptr(d.u), 1e-5, be.stream) == 1
