@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the per-sub-step RHS + pressure hot path (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" = one full evaluation of  cyclic halo -> Diff::exec_viscosity -> Advec::exec + Diff::exec (fused) ->
+Pres::exec  on synthetic drycblles-shaped fields already resident in HBM. value = interior cells of the whole
+job / max-over-ranks time per step. Strong scaling: the same global grid is slab-decomposed in y over N ranks.
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+
+WORKLOADS = {
+    "drycblles512": ("drycblles", 512, 512, 512, "drycblles 512^3 fp64, advec_2i5 + diff_smag2 + pres_2 (BASELINE.json configs[3] grid on N GPUs)"),
+    "drycblles256": ("drycblles", 256, 256, 256, "drycblles 256^3 fp64, advec_2i5 + diff_smag2 + pres_2 (BASELINE.json configs[1])"),
+    "moser600": ("moser600", 512, 256, 256, "moser600 512x256x256 fp64, advec_4 + diff_4 + pres_4 (BASELINE.json configs[2])"),
+    "taylorgreen64": ("taylorgreen", 64, 64, 64, "taylorgreen 64^3 fp64, advec_2 + diff_2 + pres_2 (BASELINE.json configs[0])"),
+}
+
+
+def cpu_baseline(case, sample=(128, 128, 128), reps=3):
+    """The CPU oracle (port of the reference CPU path, -O3 -march=native, 1 thread) on a bounded sample of the
+    same workload. Reported beside the GPU number; never part of the measured product path."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import common as cm
+    from common import ptr, dbl
+    from microhh_amd.model import CASES
+    cfg = CASES[case]
+    it, jt, kt = sample
+    g = cm.Grid(it, jt, kt, *cfg["size"], order=cfg["order"], igc=cfg["gc"][0], jgc=cfg["gc"][1], kgc=cfg["gc"][2],
+                z=(cm.moser_z(kt, cfg["size"][2]) if case == "moser600" else None))
+    c = cm.Case(g, nscalars=max(cfg["nscalars"], 0), rho="one", periodic=True)
+    O = cm.oracle(perf=True); G = g.host_struct()
+    thref = np.full(g.kcells, 300.)
+    n2 = np.zeros(g.shape3); pk = np.zeros((kt, jt, it))
+    a = (ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.rhoref), ptr(c.rhorefh))
+    adv, dif, sm = cfg["advec"], cfg["diff"], cfg["sm"]
+
+    def step():
+        for f in [c.u, c.v, c.w] + c.s[:cfg["nscalars"]]:
+            O.orc_boundary_cyclic(G, ptr(f), 2)
+        if dif == 22:
+            O.orc_smag2_strain2(G, sm, ptr(c.evisc), ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.dudz), ptr(c.dvdz))
+            O.orc_calc_N2(G, ptr(n2), ptr(c.s[0]), ptr(thref), dbl(9.81))
+            O.orc_smag2_evisc(G, sm, ptr(c.evisc), ptr(n2), ptr(c.dbdz), ptr(c.z0m), dbl(0.23), dbl(1./3.))
+        O.orc_advec_u(G, adv, ptr(c.ut), *a); O.orc_advec_v(G, adv, ptr(c.vt), *a); O.orc_advec_w(G, adv, ptr(c.wt), *a)
+        for n in range(cfg["nscalars"]):
+            O.orc_advec_s(G, adv, ptr(c.st[n]), ptr(c.s[n]), *a)
+        if dif == 22:
+            O.orc_smag2_diff_u(G, sm, ptr(c.ut), ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.evisc), ptr(c.u_fluxbot), ptr(c.u_fluxtop), ptr(c.rhoref), ptr(c.rhorefh), dbl(1e-5))
+            O.orc_smag2_diff_v(G, sm, ptr(c.vt), ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.evisc), ptr(c.v_fluxbot), ptr(c.v_fluxtop), ptr(c.rhoref), ptr(c.rhorefh), dbl(1e-5))
+            O.orc_smag2_diff_w(G, ptr(c.wt), ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.evisc), ptr(c.rhoref), ptr(c.rhorefh), dbl(1e-5))
+            for n in range(cfg["nscalars"]):
+                O.orc_smag2_diff_c(G, sm, ptr(c.st[n]), ptr(c.s[n]), ptr(c.evisc), ptr(c.s_fluxbot), ptr(c.s_fluxtop), ptr(c.rhoref), ptr(c.rhorefh), dbl(1./3.), dbl(1e-5))
+        else:
+            o = 2 if dif == 2 else 4
+            O.orc_diff_c(G, o, ptr(c.ut), ptr(c.u), dbl(1e-5)); O.orc_diff_c(G, o, ptr(c.vt), ptr(c.v), dbl(1e-5)); O.orc_diff_w(G, o, ptr(c.wt), ptr(c.w), dbl(1e-5))
+        O.orc_pres_exec(G, cfg["pres"], ptr(c.p), ptr(pk), ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.ut), ptr(c.vt), ptr(c.wt), ptr(c.rhoref), ptr(c.rhorefh), dbl(1.0))
+    step()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); step(); ts.append(time.perf_counter() - t0)
+    t = float(np.median(ts))
+    return {"value": it*jt*kt / t, "unit": "grid-cell updates/s", "cores": 1, "kind": "port",
+            "sample": "%s %dx%dx%d sub-domain of the same case, %d reps median, oracle built -O3 -march=native (pres FFT: oracle radix-2, not FFTW); box has %d cores"
+                      % (case, it, jt, kt, reps, os.cpu_count() or 0)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="drycblles512", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unfused", action="store_true", help="time Advec::exec + Diff::exec as separate launches")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched through torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    case, itot, jtot, ktot, desc = WORKLOADS[args.workload]
+    if world == 1:
+        from microhh_amd.model import HotPath
+        hp = HotPath(case, itot, jtot, ktot, device="cuda:%d" % local)
+    else:
+        from microhh_amd.slab import SlabHotPath
+        hp = SlabHotPath(case, itot, jtot, ktot, device="cuda:%d" % local)
+
+    rhs = hp.rhs_unfused if args.unfused else hp.rhs
+
+    def one_step(ev=None):
+        hp.cyclic_prognostic()
+        hp.exec_viscosity()
+        if ev is not None:
+            ev[0].record()
+        rhs()
+        if ev is not None:
+            ev[1].record()
+        hp.pres()
+
+    for _ in range(args.warmup):
+        one_step()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for n in range(args.steps):
+        one_step(events[n])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms = 1e3 * elapsed / args.steps
+    cells = itot * jtot * ktot
+    rhs_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))      # fused RHS kernel, this rank, ms per launch
+    local_cells = hp.grid.imax * hp.grid.jmax * hp.grid.kmax
+    alg_bytes = hp.alg_bytes_rhs() * local_cells
+    achieved = alg_bytes / (rhs_ms * 1e-3) / 1e9
+    out = {
+        "metric": "grid-cell updates/sec (full RHS+pres step)", "value": cells / (elapsed / args.steps), "unit": "grid-cell updates/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": desc, "grid": [itot, jtot, ktot], "decomposition": "slab-y npx=1 npy=%d" % world,
+                   "rhs": "unfused" if args.unfused else "fused"},
+        "roofline": {"bound": "hbm", "kernel": "fused RHS (advec+diff) pass" if not args.unfused else "advec+diff launches",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "alg_bytes_per_cell": hp.alg_bytes_rhs(), "ms_per_launch": rhs_ms},
+        "alg_bytes_per_cell_full_step": hp.alg_bytes_rhs() + hp.alg_bytes_visc() + hp.alg_bytes_pres(),
+        "hbm_frac_full_step": (hp.alg_bytes_rhs() + hp.alg_bytes_visc() + hp.alg_bytes_pres()) * local_cells / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(case)
+    hp.close()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
