@@ -100,12 +100,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     case, itot, jtot, ktot, desc = WORKLOADS[args.workload]
-    if world == 1:
-        from microhh_amd.model import HotPath
-        hp = HotPath(case, itot, jtot, ktot, device="cuda:%d" % local)
-    else:
-        from microhh_amd.slab import SlabHotPath
-        hp = SlabHotPath(case, itot, jtot, ktot, device="cuda:%d" % local)
+    from microhh_amd.model import HotPath
+    hp = HotPath(case, itot, jtot, ktot, device="cuda:%d" % local, npy=world, rank=rank)   # slab in y: npx=1, npy=world
 
     rhs = hp.rhs_unfused if args.unfused else hp.rhs
 

@@ -217,12 +217,33 @@ int mhh_pres_output(mhh_pres_plan* plan, const mhh_grid* g, const mhh_fields* f,
 /* Pres::check_divergence (src/pres_2.cxx:391-422, pres_4.cxx:733-767); synchronises stream */
 int mhh_pres_check_divergence(const mhh_grid* g, int order, const mhh_fields* f, void* work, double* div_out, void* stream);
 
-/* slab-decomposed (npy>1) pressure stages: local pieces either side of the x<->y all-to-all
- * (Transpose::exec_xy / exec_yx, src/transpose.cxx:170-219). Buffers are packed
- * [rank-block][k][j][i] so that one all_to_all_single moves them.                          */
-int mhh_pres_fwd_x_pack (mhh_pres_plan* plan, const mhh_grid* g, void* p_packed, void* sendbuf, void* stream);
-int mhh_pres_fwd_y_solve_bwd_y(mhh_pres_plan* plan, const mhh_grid* g, void* recvbuf, void* sendbuf, void* stream);
-int mhh_pres_bwd_x_unpack(mhh_pres_plan* plan, const mhh_grid* g, void* recvbuf, const mhh_fields* f, void* stream);
+/* plan-free forms of the pointwise stages (used by the slab driver; with npy > 1 the north-south halo of vt
+ * is the caller's exchange, the east-west wrap of ut stays local) */
+int mhh_pres_input_packed(const mhh_grid* g, int order, const mhh_fields* f, double dt, void* p_packed, void* stream);
+int mhh_pres_output_order(const mhh_grid* g, int order, const mhh_fields* f, void* stream);
+
+/* ---- Slab decomposition in y over the GPUs of one node (npx = 1, npy = N; the reference has no multi-GPU
+ * mode, its CPU-MPI path is the model: src/boundary_cyclic.cxx:116-176, src/transpose.cxx:170-219,
+ * src/fft.cxx:451-583, src/pres_2.cxx:297-299). The library packs/unpacks; the HOST issues the exchanges
+ * (ring send/recv for halos, all-to-all for the x<->y transpose) with RCCL through torch.distributed.
+ * With npy > 1, mhh_boundary_cyclic* only accept MHH_EDGE_EW and the operators that end in a cyclic fill
+ * (exec_viscosity, evisc) do the east-west wrap only.                                                     */
+/* halo buffers: [field][k][jgc][icells]; send_south = southernmost interior rows (-> south neighbour's north
+ * ghosts), send_north = northernmost interior rows (-> north neighbour's south ghosts)                     */
+unsigned long long mhh_halo_buffer_elems(const mhh_grid* g, int nfields);
+int mhh_halo_pack_ns  (const mhh_grid* g, void* const* fields, int nfields, void* send_south, void* send_north, void* stream);
+int mhh_halo_unpack_ns(const mhh_grid* g, void* const* fields, int nfields, const void* recv_from_south, const void* recv_from_north, void* stream);
+/* pres_2 split at the transposes. All-to-all buffers hold mhh_pres_slab_xbuf_elems() COMPLEX elements,
+ * laid out [peer][k][jl][kxl] so that one equal-split all_to_all moves them.                               */
+typedef struct mhh_pres_slab_plan mhh_pres_slab_plan;
+int  mhh_pres_slab_plan_create(const mhh_grid* g, const void* host_dz, const void* host_dzhi,
+                               const void* host_rhoref, const void* host_rhorefh, mhh_pres_slab_plan** out);
+void mhh_pres_slab_plan_destroy(mhh_pres_slab_plan* plan);
+unsigned long long mhh_pres_slab_xbuf_elems(const mhh_pres_slab_plan* plan);
+void* mhh_pres_slab_packed(mhh_pres_slab_plan* plan);   /* plan-owned packed-divergence buffer (imax*jmax*kmax) */
+int mhh_pres_fwd_x_pack       (mhh_pres_slab_plan* plan, const mhh_grid* g, void* p_packed, void* sendbuf, void* stream);
+int mhh_pres_fwd_y_solve_bwd_y(mhh_pres_slab_plan* plan, const mhh_grid* g, void* recvbuf, void* sendbuf, void* stream);
+int mhh_pres_bwd_x_unpack     (mhh_pres_slab_plan* plan, const mhh_grid* g, void* recvbuf, const mhh_fields* f, void* stream);
 
 /* ---- Timeloop RK3/RK4 substep (src/timeloop.cxx:250-334, src/timeloop.cu:35-122) -------- */
 int mhh_rk_substep(const mhh_grid* g, int rkorder, int substep, double dt, void* a, void* at, void* stream);

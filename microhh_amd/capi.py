@@ -71,6 +71,18 @@ SIGNATURES = {
     "mhh_pres_output": (ci, [PLAN, GP, FP, vp]),
     "mhh_pres_check_divergence": (ci, [GP, ci, FP, vp, C.POINTER(cd), vp]),
     "mhh_rk_substep": (ci, [GP, ci, ci, cd, vp, vp, vp]),
+    "mhh_pres_input_packed": (ci, [GP, ci, FP, cd, vp, vp]),
+    "mhh_pres_output_order": (ci, [GP, ci, FP, vp]),
+    "mhh_halo_buffer_elems": (C.c_ulonglong, [GP, ci]),
+    "mhh_halo_pack_ns": (ci, [GP, C.POINTER(vp), ci, vp, vp, vp]),
+    "mhh_halo_unpack_ns": (ci, [GP, C.POINTER(vp), ci, vp, vp, vp]),
+    "mhh_pres_slab_plan_create": (ci, [GP, vp, vp, vp, vp, C.POINTER(PLAN)]),
+    "mhh_pres_slab_plan_destroy": (None, [PLAN]),
+    "mhh_pres_slab_xbuf_elems": (C.c_ulonglong, [PLAN]),
+    "mhh_pres_slab_packed": (vp, [PLAN]),
+    "mhh_pres_fwd_x_pack": (ci, [PLAN, GP, vp, vp, vp]),
+    "mhh_pres_fwd_y_solve_bwd_y": (ci, [PLAN, GP, vp, vp, vp]),
+    "mhh_pres_bwd_x_unpack": (ci, [PLAN, GP, vp, FP, vp]),
 }
 
 

@@ -242,17 +242,16 @@ struct WtGhostOp
     }
 };
 
-MHH_API int mhh_pres_input(mhh_pres_plan* P, const mhh_grid* g, const mhh_fields* f, double dt, void* p_packed, void* stream)
+// plan-free form, also used by the slab-decomposed driver (there the north-south halo of vt is the caller's exchange)
+MHH_API int mhh_pres_input_packed(const mhh_grid* g, int order, const mhh_fields* f, double dt, void* p_packed, void* stream)
 {
     if (int e = check_grid(g)) return e;
-    MHH_REQUIRE(P && f && f->u && f->v && f->w && f->ut && f->vt && f->wt, "null field");
-    MHH_REQUIRE(P->dtype == g->dtype && P->itot == g->itot && P->jtot == g->jtot && P->ktot == g->ktot, "plan/grid mismatch");
+    MHH_REQUIRE(f && f->u && f->v && f->w && f->ut && f->vt && f->wt && p_packed, "null field");
+    MHH_REQUIRE(order == 2 || order == 4, "order");
     MHH_REQUIRE(dt > 0., "dt");
-    if (!p_packed) p_packed = P->packed;
-    const int order = P->order;
     MHH_REQUIRE(order == 4 || (f->rhoref && f->rhorefh), "rhoref");
     if (int e = mhh_boundary_cyclic(g, f->ut, MHH_EDGE_EW, stream)) return e;
-    if (order == 2 || g->jtot != 1)
+    if (g->npy == 1 && (order == 2 || g->jtot != 1))
         if (int e = mhh_boundary_cyclic(g, f->vt, MHH_EDGE_NS, stream)) return e;
     hipStream_t st = as_stream(stream);
 #define CALL(TF) [&]{ GridDev<TF> gd = make_grid<TF>(g); \
@@ -262,6 +261,12 @@ MHH_API int mhh_pres_input(mhh_pres_plan* P, const mhh_grid* g, const mhh_fields
         return launch_interior(st, gd, g->kstart, g->kend, op); }()
     return MHH_DISPATCH(g, CALL);
 #undef CALL
+}
+MHH_API int mhh_pres_input(mhh_pres_plan* P, const mhh_grid* g, const mhh_fields* f, double dt, void* p_packed, void* stream)
+{
+    MHH_REQUIRE(P != nullptr, "plan");
+    MHH_REQUIRE(g && P->dtype == g->dtype && P->itot == g->itot && P->jtot == g->jtot && P->ktot == g->ktot, "plan/grid mismatch");
+    return mhh_pres_input_packed(g, P->order, f, dt, p_packed ? p_packed : P->packed, stream);
 }
 
 // =======================================================================================================
@@ -509,11 +514,17 @@ struct PresOutOp
         }
     }
 };
+MHH_API int mhh_pres_output_order(const mhh_grid* g, int order, const mhh_fields* f, void* stream);
 MHH_API int mhh_pres_output(mhh_pres_plan* P, const mhh_grid* g, const mhh_fields* f, void* stream)
 {
+    MHH_REQUIRE(P != nullptr, "plan");
+    return mhh_pres_output_order(g, P->order, f, stream);
+}
+MHH_API int mhh_pres_output_order(const mhh_grid* g, int order, const mhh_fields* f, void* stream)
+{
     if (int e = check_grid(g)) return e;
-    MHH_REQUIRE(P && f && f->p && f->ut && f->vt && f->wt, "null field");
-    const int order = P->order;
+    MHH_REQUIRE(f && f->p && f->ut && f->vt && f->wt, "null field");
+    MHH_REQUIRE(order == 2 || order == 4, "order");
 #define CALL(TF) [&]{ PresOutOp<TF> op{make_grid<TF>(g), order, mp<TF>(f->ut), mp<TF>(f->vt), mp<TF>(f->wt), cp<TF>(f->p)}; \
                       return launch_interior(as_stream(stream), op.g, g->kstart, g->kend, op); }()
     return MHH_DISPATCH(g, CALL);

@@ -169,7 +169,8 @@ MHH_API int mhh_diff_exec_viscosity(const mhh_grid* g, int scheme, const mhh_fie
                       return MHH_OK; }()
     if (int e = MHH_DISPATCH(g, CALL)) return e;
 #undef CALL
-    return mhh_boundary_cyclic(g, f->evisc, MHH_EDGE_BOTH, stream);
+    // slab-decomposed: only the local east-west wrap; the caller exchanges the north-south halo
+    return mhh_boundary_cyclic(g, f->evisc, g->npy > 1 ? MHH_EDGE_EW : MHH_EDGE_BOTH, stream);
 }
 
 // Diff::exec (src/diff_2.cxx:150-180, src/diff_4.cxx:250-300, src/diff_smag2.cxx:939-1043), unfused

@@ -1,0 +1,378 @@
+// k_slab.hip -- the pieces of the hot path that differ when the grid is slab-decomposed in y over the GPUs of
+// a node (npx = 1, npy = N): north-south halo pack/unpack around the neighbour exchange, and
+// the pressure solver split at the x<->y transpose. The exchanges themselves (ring send/recv, all-to-all)
+// are issued by the host through torch.distributed (RCCL over xGMI); nothing here communicates.
+//
+// Reference semantics: Boundary_cyclic::exec's MPI path (src/boundary_cyclic.cxx:116-176) and the FFT/solve
+// sequence of src/fft.cxx:451-583 with npx = 1, where only Transpose::exec_xy / exec_yx move data
+// (src/transpose.cxx:170-219) and Pres_2::solve swaps the mode indices (src/pres_2.cxx:297-299).
+#include <vector>
+#include <rocfft/rocfft.h>
+#include "k_common.h"
+
+using namespace mhh;
+
+#define MHH_FFT_TRY(expr) do { rocfft_status s_ = (expr); if (s_ != rocfft_status_success) { \
+    mhh::set_error("FFT error: %s returned %d (%s:%d)", #expr, (int)s_, __FILE__, __LINE__); return MHH_EFFT; } } while (0)
+
+// =======================================================================================================
+// North-south halo: buffers are [field][k][jg][i] with all icells (x ghosts included, so corners are right
+// once the east-west fill has run first, like the reference's ordering).
+// =======================================================================================================
+constexpr int MAXF = 8;
+template<class TF> struct FieldList { TF* f[MAXF]; };
+
+template<class TF, bool PACK>
+__global__ void __launch_bounds__(256) halo_ns_kernel(FieldList<TF> fl, TF* __restrict__ south, TF* __restrict__ north,
+                                                      int icells, int ijcells, int kcells, int jgc, int jstart, int jend)
+{
+    const int i = blockIdx.x*256 + threadIdx.x;
+    const int k = blockIdx.y, n = blockIdx.z;
+    if (i >= icells) return;
+    TF* __restrict__ a = fl.f[n] + (size_t)k*ijcells;
+    const size_t b = ((size_t)n*kcells + k) * jgc * icells + i;
+    for (int j=0; j<jgc; ++j)
+    {
+        if (PACK)
+        {
+            south[b + (size_t)j*icells] = a[i + (jstart + j)*icells];        // my southernmost interior rows -> south neighbour's north ghosts
+            north[b + (size_t)j*icells] = a[i + (jend - jgc + j)*icells];    // my northernmost interior rows -> north neighbour's south ghosts
+        }
+        else
+        {
+            a[i + j*icells] = south[b + (size_t)j*icells];                   // south ghosts <- what the south neighbour sent north
+            a[i + (jend + j)*icells] = north[b + (size_t)j*icells];          // north ghosts <- what the north neighbour sent south
+        }
+    }
+}
+template<class TF, bool PACK>
+static int halo_launch(const mhh_grid* g, void* const* fields, int nf, void* south, void* north, hipStream_t st)
+{
+    FieldList<TF> fl;
+    for (int n=0; n<MAXF; ++n) fl.f[n] = mp<TF>(fields[n < nf ? n : 0]);
+    hipLaunchKernelGGL((halo_ns_kernel<TF, PACK>), dim3((g->icells + 255)/256, g->kcells, nf), dim3(256), 0, st, fl, mp<TF>(south), mp<TF>(north),
+                       g->icells, g->ijcells, g->kcells, g->jgc, g->jstart, g->jend);
+    MHH_LAUNCH_CHECK();
+    return MHH_OK;
+}
+static int halo_check(const mhh_grid* g, void* const* fields, int nf, const void* a, const void* b)
+{
+    if (int e = check_grid(g)) return e;
+    MHH_REQUIRE(nf >= 1 && nf <= MAXF && fields && a && b, "1..8 fields, non-null buffers");
+    for (int n=0; n<nf; ++n) MHH_REQUIRE(fields[n] != nullptr, "null field");
+    MHH_REQUIRE(g->jmax >= g->jgc, "jmax >= jgc (src/grid.cxx:420)");
+    return MHH_OK;
+}
+MHH_API int mhh_halo_pack_ns(const mhh_grid* g, void* const* fields, int nf, void* send_south, void* send_north, void* stream)
+{
+    if (int e = halo_check(g, fields, nf, send_south, send_north)) return e;
+    if (g->dtype == MHH_F64) return halo_launch<double, true>(g, fields, nf, send_south, send_north, as_stream(stream));
+    return halo_launch<float, true>(g, fields, nf, send_south, send_north, as_stream(stream));
+}
+MHH_API int mhh_halo_unpack_ns(const mhh_grid* g, void* const* fields, int nf, const void* recv_south, const void* recv_north, void* stream)
+{
+    if (int e = halo_check(g, fields, nf, recv_south, recv_north)) return e;
+    if (g->dtype == MHH_F64) return halo_launch<double, false>(g, fields, nf, const_cast<void*>(recv_south), const_cast<void*>(recv_north), as_stream(stream));
+    return halo_launch<float, false>(g, fields, nf, const_cast<void*>(recv_south), const_cast<void*>(recv_north), as_stream(stream));
+}
+MHH_API unsigned long long mhh_halo_buffer_elems(const mhh_grid* g, int nf)
+{
+    return (unsigned long long)nf * g->kcells * g->jgc * g->icells;
+}
+
+// =======================================================================================================
+// Slab pressure solver (pres_2). Layouts, all complex interleaved, nxh = itot/2+1, nxb = ceil(nxh/npy):
+//   specx [k][jl][kx]            after the local x transform (jl in this rank's jmax rows)
+//   xbuf  [q][k][jl][kxl]        all-to-all buffer, q = destination / source rank, kx = q*nxb + kxl (zero padded)
+//   specy [k][kxl][j]            after the exchange, j over the full jtot, unit stride for the y transform
+// =======================================================================================================
+template<class TF> struct C2 { TF x, y; };
+
+struct mhh_pres_slab_plan
+{
+    int dtype = 0, itot = 0, jtot = 0, ktot = 0, jmax = 0, npy = 1, rank = 0, nxh = 0, nxb = 0;
+    size_t esz = 8;
+    void* bmati = nullptr; void* bmatj = nullptr; void* a = nullptr; void* c = nullptr; void* dz = nullptr; void* rhoref = nullptr;
+    void* packed = nullptr; void* specx = nullptr; void* specy = nullptr; void* work = nullptr;
+    rocfft_plan fx = nullptr, bx = nullptr, fy = nullptr, by = nullptr;
+    rocfft_execution_info info = nullptr;
+    void* wb = nullptr; size_t wbs = 0;
+};
+
+template<class TF>
+static int up(void** dst, const std::vector<TF>& v)
+{
+    MHH_HIP_TRY(hipMalloc(dst, v.size()*sizeof(TF)));
+    MHH_HIP_TRY(hipMemcpy(*dst, v.data(), v.size()*sizeof(TF), hipMemcpyHostToDevice));
+    return MHH_OK;
+}
+template<class TF>
+static int slab_tables(mhh_pres_slab_plan* P, const mhh_grid* g, const void* hdz, const void* hdzhi, const void* hrho, const void* hrhoh)
+{
+    // Pres_2::set_values, src/pres_2.cxx:125-153
+    const int itot = g->itot, jtot = g->jtot, kmax = g->kmax, kgc = g->kgc;
+    const TF dx = TF(g->dx), dy = TF(g->dy);
+    const TF dxidxi = 1./(dx*dx), dyidyi = 1./(dy*dy);
+    const TF pi = std::acos(-1.);
+    std::vector<TF> bi(itot), bj(jtot), a(kmax), c(kmax), dzk(kmax), rk(kmax);
+    for (int j=0; j<jtot/2+1; ++j) bj[j] = 2. * (std::cos(2.*pi*(TF)j/(TF)jtot)-1.) * dyidyi;
+    for (int j=jtot/2+1; j<jtot; ++j) bj[j] = bj[jtot-j];
+    for (int i=0; i<itot/2+1; ++i) bi[i] = 2. * (std::cos(2.*pi*(TF)i/(TF)itot)-1.) * dxidxi;
+    for (int i=itot/2+1; i<itot; ++i) bi[i] = bi[itot-i];
+    const TF* dz = cp<TF>(hdz); const TF* dzhi = cp<TF>(hdzhi); const TF* rhoh = cp<TF>(hrhoh); const TF* rho = cp<TF>(hrho);
+    for (int k=0; k<kmax; ++k)
+    {
+        a[k] = dz[k+kgc] * rhoh[k+kgc  ]*dzhi[k+kgc  ];
+        c[k] = dz[k+kgc] * rhoh[k+kgc+1]*dzhi[k+kgc+1];
+        dzk[k] = dz[k+kgc]; rk[k] = rho[k+kgc];
+    }
+    if (int e = up(&P->bmati, bi)) return e;
+    if (int e = up(&P->bmatj, bj)) return e;
+    if (int e = up(&P->a, a)) return e;
+    if (int e = up(&P->c, c)) return e;
+    if (int e = up(&P->dz, dzk)) return e;
+    return up(&P->rhoref, rk);
+}
+
+static int plan1d(rocfft_plan* plan, rocfft_transform_type type, rocfft_result_placement place, int dtype, size_t n, size_t batch,
+                  rocfft_array_type in_t, rocfft_array_type out_t, size_t in_dist, size_t out_dist, size_t* wbs)
+{
+    const size_t len[1] = {n}, one[1] = {1}, off[1] = {0};
+    rocfft_plan_description d = nullptr;
+    MHH_FFT_TRY(rocfft_plan_description_create(&d));
+    MHH_FFT_TRY(rocfft_plan_description_set_data_layout(d, in_t, out_t, off, off, 1, one, in_dist, 1, one, out_dist));
+    MHH_FFT_TRY(rocfft_plan_create(plan, place, type, dtype == MHH_F64 ? rocfft_precision_double : rocfft_precision_single, 1, len, batch, d));
+    MHH_FFT_TRY(rocfft_plan_description_destroy(d));
+    size_t w = 0;
+    MHH_FFT_TRY(rocfft_plan_get_work_buffer_size(*plan, &w));
+    if (w > *wbs) *wbs = w;
+    return MHH_OK;
+}
+
+MHH_API void mhh_pres_slab_plan_destroy(mhh_pres_slab_plan* P)
+{
+    if (!P) return;
+    for (rocfft_plan p : {P->fx, P->bx, P->fy, P->by}) if (p) rocfft_plan_destroy(p);
+    if (P->info) rocfft_execution_info_destroy(P->info);
+    for (void* b : {P->bmati, P->bmatj, P->a, P->c, P->dz, P->rhoref, P->packed, P->specx, P->specy, P->work, P->wb}) if (b) (void)hipFree(b);
+    delete P;
+}
+
+MHH_API int mhh_pres_slab_plan_create(const mhh_grid* g, const void* host_dz, const void* host_dzhi, const void* host_rhoref, const void* host_rhorefh,
+                                      mhh_pres_slab_plan** out)
+{
+    if (int e = check_grid(g)) return e;
+    MHH_REQUIRE(out && host_dz && host_dzhi && host_rhoref && host_rhorefh, "null pointer");
+    MHH_REQUIRE(g->npy >= 1 && g->jtot % g->npy == 0 && g->jmax == g->jtot / g->npy && g->imax == g->itot, "slab grid: jmax = jtot/npy, imax = itot");
+    MHH_REQUIRE(g->mpicoordy >= 0 && g->mpicoordy < g->npy, "mpicoordy");
+    MHH_REQUIRE(g->jtot > 1 && g->kgc >= 1 && g->igc >= 1 && g->jgc >= 1, "pres_2 slab needs a 3-D grid with 1 ghost cell");
+    mhh_pres_slab_plan* P = new mhh_pres_slab_plan();
+    P->dtype = g->dtype; P->itot = g->itot; P->jtot = g->jtot; P->ktot = g->ktot; P->jmax = g->jmax; P->npy = g->npy; P->rank = g->mpicoordy;
+    P->nxh = g->itot/2 + 1; P->nxb = (P->nxh + g->npy - 1) / g->npy; P->esz = (g->dtype == MHH_F64) ? 8 : 4;
+    int e = (g->dtype == MHH_F64) ? slab_tables<double>(P, g, host_dz, host_dzhi, host_rhoref, host_rhorefh)
+                                  : slab_tables<float>(P, g, host_dz, host_dzhi, host_rhoref, host_rhorefh);
+    const size_t nreal = (size_t)g->itot*g->jmax*g->ktot, nx = (size_t)P->nxh*g->jmax*g->ktot, ny = (size_t)P->nxb*g->jtot*g->ktot;
+    auto alloc = [&](void** p, size_t bytes) { if (e) return; hipError_t h = hipMalloc(p, bytes); if (h != hipSuccess) { set_error("hipMalloc: %s", hipGetErrorString(h)); e = MHH_ENOMEM; } };
+    alloc(&P->packed, nreal*P->esz); alloc(&P->specx, nx*2*P->esz); alloc(&P->specy, ny*2*P->esz); alloc(&P->work, ny*P->esz);
+    if (!e)
+    {
+        rocfft_setup();
+        const rocfft_array_type R = rocfft_array_type_real, H = rocfft_array_type_hermitian_interleaved, Cx = rocfft_array_type_complex_interleaved;
+        const size_t bx = (size_t)g->jmax*g->ktot, by = (size_t)P->nxb*g->ktot;
+        e = plan1d(&P->fx, rocfft_transform_type_real_forward, rocfft_placement_notinplace, g->dtype, g->itot, bx, R, H, g->itot, P->nxh, &P->wbs);
+        if (!e) e = plan1d(&P->bx, rocfft_transform_type_real_inverse, rocfft_placement_notinplace, g->dtype, g->itot, bx, H, R, P->nxh, g->itot, &P->wbs);
+        if (!e) e = plan1d(&P->fy, rocfft_transform_type_complex_forward, rocfft_placement_inplace, g->dtype, g->jtot, by, Cx, Cx, g->jtot, g->jtot, &P->wbs);
+        if (!e) e = plan1d(&P->by, rocfft_transform_type_complex_inverse, rocfft_placement_inplace, g->dtype, g->jtot, by, Cx, Cx, g->jtot, g->jtot, &P->wbs);
+        if (!e && rocfft_execution_info_create(&P->info) != rocfft_status_success) { set_error("FFT error: execution_info_create"); e = MHH_EFFT; }
+        if (!e && P->wbs)
+        {
+            alloc(&P->wb, P->wbs);
+            if (!e && rocfft_execution_info_set_work_buffer(P->info, P->wb, P->wbs) != rocfft_status_success) { set_error("FFT error: set_work_buffer"); e = MHH_EFFT; }
+        }
+    }
+    if (e) { mhh_pres_slab_plan_destroy(P); return e; }
+    *out = P;
+    return MHH_OK;
+}
+MHH_API unsigned long long mhh_pres_slab_xbuf_elems(const mhh_pres_slab_plan* P)   // complex elements of one all-to-all buffer
+{
+    return (unsigned long long)P->npy * P->ktot * P->jmax * P->nxb;
+}
+MHH_API void* mhh_pres_slab_packed(mhh_pres_slab_plan* P) { return P->packed; }
+
+// specx [k][jl][kx] -> xbuf [q][k][jl][kxl] (FWD) and back (the reverse direction drops the zero padding)
+template<class TF, bool FWD>
+__global__ void __launch_bounds__(256) xbuf_x_kernel(C2<TF>* __restrict__ specx, C2<TF>* __restrict__ xbuf, int nxh, int nxb, int jmax, int ktot, int npy)
+{
+    const int kx = blockIdx.x*256 + threadIdx.x;          // 0 .. npy*nxb-1
+    const int jl = blockIdx.y, k = blockIdx.z;
+    if (kx >= npy*nxb) return;
+    const int q = kx / nxb, kxl = kx - q*nxb;
+    const size_t xb = (((size_t)q*ktot + k)*jmax + jl)*nxb + kxl;
+    const size_t sx = ((size_t)k*jmax + jl)*nxh + kx;
+    if (FWD) xbuf[xb] = (kx < nxh) ? specx[sx] : C2<TF>{0, 0};
+    else if (kx < nxh) specx[sx] = xbuf[xb];
+}
+// xbuf [r][k][jl][kxl] <-> specy [k][kxl][j = r*jmax + jl]
+template<class TF, bool FWD>
+__global__ void __launch_bounds__(256) xbuf_y_kernel(C2<TF>* __restrict__ specy, C2<TF>* __restrict__ xbuf, int nxb, int jmax, int jtot, int ktot)
+{
+    const int j = blockIdx.x*256 + threadIdx.x;
+    const int kxl = blockIdx.y, k = blockIdx.z;
+    if (j >= jtot) return;
+    const int r = j / jmax, jl = j - r*jmax;
+    const size_t xb = (((size_t)r*ktot + k)*jmax + jl)*nxb + kxl;
+    const size_t sy = ((size_t)k*nxb + kxl)*jtot + j;
+    if (FWD) specy[sy] = xbuf[xb]; else xbuf[xb] = specy[sy];
+}
+
+// Thomas algorithm on specy, one thread per (ky, kxl) column, ky fastest (src/pres_2.cxx:289-330, :202-263)
+template<class TF>
+__global__ void __launch_bounds__(64) tdma_slab_kernel(C2<TF>* __restrict__ p, TF* __restrict__ work3d,
+                                                       const TF* __restrict__ bmati, const TF* __restrict__ bmatj,
+                                                       const TF* __restrict__ a, const TF* __restrict__ c, const TF* __restrict__ dz, const TF* __restrict__ rho,
+                                                       int nxh, int nxb, int kx0, int jtot, int kmax)
+{
+    const int ky = blockIdx.x*64 + threadIdx.x, kxl = blockIdx.y;
+    const int kx = kx0 + kxl;                              // swapped indices: this rank owns a block of x modes, all y modes
+    if (ky >= jtot || kx >= nxh) return;
+    const size_t kk = (size_t)nxb*jtot, col = (size_t)kxl*jtot + ky;
+    const TF bm = bmati[kx] + bmatj[ky];
+    const bool mean = (kx == 0 && ky == 0);
+    TF w2; C2<TF> pp;
+    {
+        const TF dz2 = dz[0]*dz[0];
+        TF b = dz2 * rho[0]*bm - (a[0]+c[0]);
+        b += a[0];
+        if (kmax == 1) { if (mean) b -= c[0]; else b += c[0]; }
+        C2<TF> q = p[col];
+        q.x = dz2 * q.x; q.y = dz2 * q.y;
+        w2 = b;
+        q.x /= w2; q.y /= w2;
+        p[col] = q; pp = q;
+    }
+    for (int k=1; k<kmax; ++k)
+    {
+        const size_t e = col + (size_t)k*kk;
+        const TF dz2 = dz[k]*dz[k];
+        TF b = dz2 * rho[k]*bm - (a[k]+c[k]);
+        if (k == kmax-1) { if (mean) b -= c[k]; else b += c[k]; }
+        C2<TF> q = p[e];
+        q.x = dz2 * q.x; q.y = dz2 * q.y;
+        const TF w3 = c[k-1] / w2;
+        work3d[e] = w3;
+        w2 = b - a[k]*w3;
+        q.x -= a[k]*pp.x; q.y -= a[k]*pp.y;
+        q.x /= w2; q.y /= w2;
+        p[e] = q; pp = q;
+    }
+    for (int k=kmax-2; k>=0; --k)
+    {
+        const size_t e = col + (size_t)k*kk;
+        const TF w3 = work3d[e+kk];
+        C2<TF> q = p[e];
+        q.x -= w3*pp.x; q.y -= w3*pp.y;
+        p[e] = q; pp = q;
+    }
+}
+
+// packed real [k][jl][i] -> ghosted p: interior rows + x halo (wrap) + bottom ghost level; the y halo is the caller's exchange
+template<class TF>
+__global__ void __launch_bounds__(256) unpack_slab_kernel(TF* __restrict__ p, const TF* __restrict__ packed, int itot, int jtot, int jmax, int kmax,
+                                                          int igc, int jgc, int kgc, int icells, int jcells)
+{
+    const int i = blockIdx.x*256 + threadIdx.x;
+    const int jl = blockIdx.y, kz = blockIdx.z;
+    if (i >= icells) return;
+    const int kd = (kz < kmax) ? kz + kgc : kgc - 1;
+    const int ks = (kz < kmax) ? kz : 0;
+    int is = (i - igc) % itot; if (is < 0) is += itot;
+    const TF val = packed[(size_t)is + (size_t)jl*itot + (size_t)ks*itot*jmax] / jtot / itot;
+    p[(size_t)i + (size_t)(jl + jgc)*icells + (size_t)kd*icells*jcells] = val;
+}
+
+static int slab_match(const mhh_pres_slab_plan* P, const mhh_grid* g)
+{
+    if (int e = check_grid(g)) return e;
+    MHH_REQUIRE(P && P->dtype == g->dtype && P->itot == g->itot && P->jtot == g->jtot && P->ktot == g->ktot && P->jmax == g->jmax && P->npy == g->npy && P->rank == g->mpicoordy, "plan/grid mismatch");
+    return MHH_OK;
+}
+
+// stage 1: x transform of the packed divergence + pack for the forward all-to-all
+MHH_API int mhh_pres_fwd_x_pack(mhh_pres_slab_plan* P, const mhh_grid* g, void* p_packed, void* sendbuf, void* stream)
+{
+    if (int e = slab_match(P, g)) return e;
+    MHH_REQUIRE(sendbuf != nullptr, "sendbuf");
+    if (!p_packed) p_packed = P->packed;
+    hipStream_t st = as_stream(stream);
+    MHH_FFT_TRY(rocfft_execution_info_set_stream(P->info, st));
+    void* in[1] = {p_packed}; void* out[1] = {P->specx};
+    MHH_FFT_TRY(rocfft_execute(P->fx, in, out, P->info));
+    dim3 grid((P->npy*P->nxb + 255)/256, P->jmax, P->ktot);
+    if (g->dtype == MHH_F64) hipLaunchKernelGGL((xbuf_x_kernel<double, true>), grid, dim3(256), 0, st, (C2<double>*)P->specx, (C2<double>*)sendbuf, P->nxh, P->nxb, P->jmax, P->ktot, P->npy);
+    else                     hipLaunchKernelGGL((xbuf_x_kernel<float, true>), grid, dim3(256), 0, st, (C2<float>*)P->specx, (C2<float>*)sendbuf, P->nxh, P->nxb, P->jmax, P->ktot, P->npy);
+    MHH_LAUNCH_CHECK();
+    return MHH_OK;
+}
+// stage 2: after the forward all-to-all: y transform, tridiagonal solves, inverse y transform, pack for the way back
+MHH_API int mhh_pres_fwd_y_solve_bwd_y(mhh_pres_slab_plan* P, const mhh_grid* g, void* recvbuf, void* sendbuf, void* stream)
+{
+    if (int e = slab_match(P, g)) return e;
+    MHH_REQUIRE(recvbuf && sendbuf, "buffers");
+    hipStream_t st = as_stream(stream);
+    MHH_FFT_TRY(rocfft_execution_info_set_stream(P->info, st));
+    dim3 gy((P->jtot + 255)/256, P->nxb, P->ktot);
+    dim3 gs((P->jtot + 63)/64, P->nxb);
+    void* io[1] = {P->specy};
+    if (g->dtype == MHH_F64)
+    {
+        hipLaunchKernelGGL((xbuf_y_kernel<double, true>), gy, dim3(256), 0, st, (C2<double>*)P->specy, (C2<double>*)recvbuf, P->nxb, P->jmax, P->jtot, P->ktot);
+        MHH_LAUNCH_CHECK();
+        MHH_FFT_TRY(rocfft_execute(P->fy, io, nullptr, P->info));
+        hipLaunchKernelGGL(tdma_slab_kernel<double>, gs, dim3(64), 0, st, (C2<double>*)P->specy, (double*)P->work, cp<double>(P->bmati), cp<double>(P->bmatj),
+                           cp<double>(P->a), cp<double>(P->c), cp<double>(P->dz), cp<double>(P->rhoref), P->nxh, P->nxb, P->rank*P->nxb, P->jtot, P->ktot);
+        MHH_LAUNCH_CHECK();
+        MHH_FFT_TRY(rocfft_execute(P->by, io, nullptr, P->info));
+        hipLaunchKernelGGL((xbuf_y_kernel<double, false>), gy, dim3(256), 0, st, (C2<double>*)P->specy, (C2<double>*)sendbuf, P->nxb, P->jmax, P->jtot, P->ktot);
+    }
+    else
+    {
+        hipLaunchKernelGGL((xbuf_y_kernel<float, true>), gy, dim3(256), 0, st, (C2<float>*)P->specy, (C2<float>*)recvbuf, P->nxb, P->jmax, P->jtot, P->ktot);
+        MHH_LAUNCH_CHECK();
+        MHH_FFT_TRY(rocfft_execute(P->fy, io, nullptr, P->info));
+        hipLaunchKernelGGL(tdma_slab_kernel<float>, gs, dim3(64), 0, st, (C2<float>*)P->specy, (float*)P->work, cp<float>(P->bmati), cp<float>(P->bmatj),
+                           cp<float>(P->a), cp<float>(P->c), cp<float>(P->dz), cp<float>(P->rhoref), P->nxh, P->nxb, P->rank*P->nxb, P->jtot, P->ktot);
+        MHH_LAUNCH_CHECK();
+        MHH_FFT_TRY(rocfft_execute(P->by, io, nullptr, P->info));
+        hipLaunchKernelGGL((xbuf_y_kernel<float, false>), gy, dim3(256), 0, st, (C2<float>*)P->specy, (C2<float>*)sendbuf, P->nxb, P->jmax, P->jtot, P->ktot);
+    }
+    MHH_LAUNCH_CHECK();
+    return MHH_OK;
+}
+// stage 3: after the backward all-to-all: inverse x transform, normalise, write p (interior rows, x halo, bottom ghost level)
+MHH_API int mhh_pres_bwd_x_unpack(mhh_pres_slab_plan* P, const mhh_grid* g, void* recvbuf, const mhh_fields* f, void* stream)
+{
+    if (int e = slab_match(P, g)) return e;
+    MHH_REQUIRE(recvbuf && f && f->p, "buffers");
+    hipStream_t st = as_stream(stream);
+    MHH_FFT_TRY(rocfft_execution_info_set_stream(P->info, st));
+    dim3 grid((P->npy*P->nxb + 255)/256, P->jmax, P->ktot);
+    dim3 ug((g->icells + 255)/256, g->jmax, g->kmax + 1);
+    void* in[1] = {P->specx}; void* out[1] = {P->packed};
+    if (g->dtype == MHH_F64)
+    {
+        hipLaunchKernelGGL((xbuf_x_kernel<double, false>), grid, dim3(256), 0, st, (C2<double>*)P->specx, (C2<double>*)recvbuf, P->nxh, P->nxb, P->jmax, P->ktot, P->npy);
+        MHH_LAUNCH_CHECK();
+        MHH_FFT_TRY(rocfft_execute(P->bx, in, out, P->info));
+        hipLaunchKernelGGL(unpack_slab_kernel<double>, ug, dim3(256), 0, st, mp<double>(f->p), cp<double>(P->packed), g->itot, g->jtot, g->jmax, g->kmax, g->igc, g->jgc, g->kgc, g->icells, g->jcells);
+    }
+    else
+    {
+        hipLaunchKernelGGL((xbuf_x_kernel<float, false>), grid, dim3(256), 0, st, (C2<float>*)P->specx, (C2<float>*)recvbuf, P->nxh, P->nxb, P->jmax, P->ktot, P->npy);
+        MHH_LAUNCH_CHECK();
+        MHH_FFT_TRY(rocfft_execute(P->bx, in, out, P->info));
+        hipLaunchKernelGGL(unpack_slab_kernel<float>, ug, dim3(256), 0, st, mp<float>(f->p), cp<float>(P->packed), g->itot, g->jtot, g->jmax, g->kmax, g->igc, g->jgc, g->kgc, g->icells, g->jcells);
+    }
+    MHH_LAUNCH_CHECK();
+    return MHH_OK;
+}

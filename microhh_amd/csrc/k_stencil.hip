@@ -90,6 +90,7 @@ MHH_API int mhh_boundary_cyclic_n(const mhh_grid* g, void* const* data, int nfie
 {
     if (int e = check_grid(g)) return e;
     MHH_REQUIRE(edge >= 0 && edge <= 2, "edge");
+    MHH_REQUIRE(g->npy == 1 || edge == MHH_EDGE_EW, "slab-decomposed grid: north-south ghosts come from the neighbour exchange (mhh_halo_pack_ns / mhh_halo_unpack_ns)");
     if (g->dtype == MHH_F64) return cyclic_launch<double>(g, data, nfields, edge, g->kcells, g->kstart, g->kend, as_stream(stream));
     return cyclic_launch<float>(g, data, nfields, edge, g->kcells, g->kstart, g->kend, as_stream(stream));
 }
@@ -409,7 +410,8 @@ static int evisc_finish(const mhh_grid* g, const GridDev<TF>& gd, int sm, void* 
         MirrorWallOp<TF> m{gd, mp<TF>(ev)};
         if (int e = launch_cells(st, m, 0, g->icells, 0, g->jcells, 0, 1, g->icells, g->ijcells)) return e;
     }
-    return mhh_boundary_cyclic(g, ev, MHH_EDGE_BOTH, st);
+    // slab-decomposed: only the local east-west wrap; the caller exchanges the north-south halo
+    return mhh_boundary_cyclic(g, ev, g->npy > 1 ? MHH_EDGE_EW : MHH_EDGE_BOTH, st);
 }
 MHH_API int mhh_smag2_evisc(const mhh_grid* g, int sm, void* ev, const void* N2, const void* bgradbot, const void* z0m,
                             const void* mlen0, double tPr, void* stream)

@@ -1,13 +1,15 @@
 """Host-side driver of one RK sub-step's hot path: the slice of ``Model<TF>::exec`` (src/model.cxx:346-411)
 that this package accelerates, expressed as calls into the C ABI.
 
-    boundary->set_prognostic_cyclic_bcs   -> mhh_boundary_cyclic_n          (src/model.cxx:346)
-    diff->exec_viscosity(thermo)          -> mhh_diff_exec_viscosity         (:354)
-    advec->exec ; diff->exec              -> mhh_rhs_exec (fused, same bits) (:388, :392)
-    pres->exec(dt)                        -> mhh_pres_exec                   (:411)
+    boundary->set_prognostic_cyclic_bcs   -> mhh_boundary_cyclic_n (+ N-S neighbour exchange)   (src/model.cxx:346)
+    diff->exec_viscosity(thermo)          -> mhh_diff_exec_viscosity (+ N-S exchange of evisc)   (:354)
+    advec->exec ; diff->exec              -> mhh_rhs_exec (fused, same bits)                     (:388, :392)
+    pres->exec(dt)                        -> mhh_pres_exec, or its slab form around 2 all-to-alls (:411)
 
-PyTorch is used for device memory and streams only; every kernel is the hand-written HIP in csrc/.
-Case recipes follow SURVEY.md §8(d): synthetic drycblles / taylorgreen / moser600 shaped inputs.
+One process per GPU. With ``npy`` > 1 the grid is slab-decomposed in y (npx = 1): halos travel as ring
+send/recv and the pressure solver's x<->y transposes as all_to_all, both through torch.distributed
+(backend "nccl" = RCCL over xGMI). PyTorch provides device memory, streams and the process group only;
+every kernel is the hand-written HIP behind the C ABI. Case recipes follow SURVEY.md §8(d).
 """
 import ctypes as C
 import math
@@ -15,77 +17,140 @@ import math
 import numpy as np
 
 from . import capi
-from .grid import Grid, ADVEC_2, ADVEC_2I5, ADVEC_4, DIFF_2, DIFF_4, DIFF_SMAG2, EDGE_BOTH, moser_z
+from .grid import Grid, ADVEC_2, ADVEC_2I5, ADVEC_4, DIFF_2, DIFF_4, DIFF_SMAG2, EDGE_BOTH, EDGE_EW, moser_z
 
 CASES = {
-    # name: (advec, diff, pres order, spatial order, ghost cells, domain, scalars, surface model)
+    # name: advec, diff, pres order, spatial order, ghost cells, domain, scalars, surface model
     "taylorgreen": dict(advec=ADVEC_2, diff=DIFF_2, pres=2, order=2, gc=(1, 1, 1), size=(1., 1., 0.5), nscalars=0, sm=0, visc=(8.*math.pi**2*1000.)**-1),
     "drycblles": dict(advec=ADVEC_2I5, diff=DIFF_SMAG2, pres=2, order=2, gc=(3, 3, 1), size=(3200., 3200., 1200.), nscalars=1, sm=1, visc=1e-5),
     "moser600": dict(advec=ADVEC_4, diff=DIFF_4, pres=4, order=4, gc=(3, 3, 3), size=(2*math.pi, math.pi, 2.), nscalars=0, sm=0, visc=1e-5),
 }
 
+FIELDS3 = ("u", "v", "w", "ut", "vt", "wt")
+SURF = ("u_fluxbot", "u_fluxtop", "v_fluxbot", "v_fluxtop", "s_fluxbot", "s_fluxtop", "dudz", "dvdz", "dbdz", "z0m")
 
-def _t(torch, dtype):
-    return torch.float64 if np.dtype(dtype) == np.float64 else torch.float32
+
+def synthetic_global(case, itot, jtot, ktot, dtype=np.float64, seed=666):
+    """Global synthetic fields on the host (interior only; ghosts are filled by the halo code). For tests that
+    compare a slab-decomposed run with a single-rank run."""
+    cfg = CASES[case]
+    rs = np.random.RandomState(seed)
+    n3, n2 = (ktot, jtot, itot), (jtot, itot)
+    out = {"u": rs.uniform(-1, 1, n3), "v": rs.uniform(-1, 1, n3), "w": rs.uniform(-.5, .5, n3),
+           "ut": rs.uniform(0, 1e-3, n3), "vt": rs.uniform(0, 1e-3, n3), "wt": rs.uniform(0, 1e-3, n3)}
+    out["w"][0] = 0; out["wt"][0] = 0
+    z = (np.arange(ktot) + 0.5) * cfg["size"][2] / ktot
+    for n in range(cfg["nscalars"]):
+        out["s%d" % n] = 300. + 0.003*z[:, None, None] + rs.uniform(-.05, .05, n3)
+        out["st%d" % n] = rs.uniform(0, 1e-4, n3)
+    for k in SURF:
+        out[k] = rs.uniform(0, 1e-4 if k == "dbdz" else 1e-2, n2)
+    out["z0m"][:] = 0.1
+    return {k: v.astype(dtype) for k, v in out.items()}
 
 
 class HotPath:
-    """Device-resident fields of one rank + the operator calls of one sub-step (single GPU)."""
+    """Device-resident fields of ONE rank + the operator calls of one sub-step."""
 
-    def __init__(self, case, itot, jtot, ktot, dtype=np.float64, device="cuda:0", seed=666, dt=1.0):
+    def __init__(self, case, itot, jtot, ktot, dtype=np.float64, device="cuda:0", seed=666, dt=1.0,
+                 lib=None, npy=1, rank=0, group=None, global_init=None, force_slab=False):
         import torch
         self.torch = torch
-        self.lib = capi.lib()
+        self.lib = lib if lib is not None else capi.lib()
         self.cfg = cfg = CASES[case]
-        self.case = case
-        self.dt = dt
+        self.case, self.dt, self.npy, self.rank, self.group = case, dt, npy, rank, group
+        # slab code path (halo pack/unpack, split pressure solve); force_slab runs it on ONE rank with the exchanges
+        # degenerated to local copies, which is how the slab kernels are exercised on a single-GPU box
+        self.slab = (npy > 1) or force_slab
         self.device = torch.device(device)
+        self.on_gpu = self.device.type == "cuda"
+        if self.slab and cfg["pres"] != 2:
+            raise ValueError("slab decomposition implements pres_2 (BASELINE.json multi-GPU configs use pres_2)")
         z = moser_z(ktot, cfg["size"][2]) if case == "moser600" else None
-        self.grid = g = Grid(itot, jtot, ktot, *cfg["size"], order=cfg["order"], igc=cfg["gc"][0], jgc=cfg["gc"][1], kgc=cfg["gc"][2], z=z, dtype=dtype)
-        self.G = g.device_struct(self.device)
-        td = _t(torch, dtype)
-        gen = torch.Generator(device=self.device); gen.manual_seed(seed)
-        n3 = g.shape3
+        self.grid = g = Grid(itot, jtot, ktot, *cfg["size"], order=cfg["order"], igc=cfg["gc"][0], jgc=cfg["gc"][1], kgc=cfg["gc"][2],
+                             z=z, dtype=dtype, npy=npy, mpicoordy=rank)
+        self.G = g.device_struct(self.device) if self.on_gpu else g.host_struct()
+        self.td = td = torch.float64 if np.dtype(dtype) == np.float64 else torch.float32
+        n3, n2 = g.shape3, g.shape2
+        if global_init is None:
+            gen = torch.Generator(device=self.device); gen.manual_seed(seed + 7919*rank)
 
-        def rnd(shape, lo=0.0, hi=1.0):
-            return (torch.rand(shape, generator=gen, device=self.device, dtype=td) * (hi - lo) + lo).contiguous()
-        self.u, self.v, self.w = rnd(n3, -1, 1), rnd(n3, -1, 1), rnd(n3, -0.5, 0.5)
-        self.w[g.kstart] = 0; self.w[g.kend:] = 0; self.w[:g.kstart] = 0
-        self.ut, self.vt, self.wt = rnd(n3, 0, 1e-3), rnd(n3, 0, 1e-3), rnd(n3, 0, 1e-3)
+            def rnd(shape, lo=0.0, hi=1.0):
+                return (torch.rand(shape, generator=gen, device=self.device, dtype=td) * (hi - lo) + lo).contiguous()
+            self.u, self.v, self.w = rnd(n3, -1, 1), rnd(n3, -1, 1), rnd(n3, -0.5, 0.5)
+            self.ut, self.vt, self.wt = rnd(n3, 0, 1e-3), rnd(n3, 0, 1e-3), rnd(n3, 0, 1e-3)
+            zc = torch.from_numpy(g.z.astype(np.float64)).to(self.device).to(td)
+            self.s = [(300. + 0.003*zc[:, None, None] + rnd(n3, -0.05, 0.05)).contiguous() for _ in range(cfg["nscalars"])]
+            self.st = [rnd(n3, 0, 1e-4) for _ in range(cfg["nscalars"])]
+            self.surf = {k: rnd(n2, 0, 1e-2) for k in SURF}
+            self.surf["dbdz"] = rnd(n2, 0, 1e-4)
+            self.surf["z0m"] = torch.full(n2, 0.1, device=self.device, dtype=td)
+        else:
+            j0 = rank * g.jmax
+
+            def put3(a):
+                t = torch.zeros(n3, dtype=td)
+                t[g.kstart:g.kend, g.jstart:g.jend, g.istart:g.iend] = torch.from_numpy(np.ascontiguousarray(a[:, j0:j0+g.jmax, :]))
+                return t.to(self.device).contiguous()
+
+            def put2(a):
+                t = torch.zeros(n2, dtype=td)
+                t[g.jstart:g.jend, g.istart:g.iend] = torch.from_numpy(np.ascontiguousarray(a[j0:j0+g.jmax, :]))
+                return t.to(self.device).contiguous()
+            for n in FIELDS3:
+                setattr(self, n, put3(global_init[n]))
+            self.s = [put3(global_init["s%d" % n]) for n in range(cfg["nscalars"])]
+            self.st = [put3(global_init["st%d" % n]) for n in range(cfg["nscalars"])]
+            self.surf = {k: put2(global_init[k]) for k in SURF}
+        # solid walls: w and its tendency vanish at kstart and above kend-1
+        self.w[:g.kstart+1] = 0; self.w[g.kend:] = 0
         self.wt[:g.kstart+1] = 0; self.wt[g.kend:] = 0
-        self.s, self.st = [], []
-        zc = torch.from_numpy(g.z.astype(np.float64)).to(self.device).to(td)
-        for _ in range(cfg["nscalars"]):
-            th = 300. + 0.003*zc[:, None, None] + rnd(n3, -0.05, 0.05)
-            self.s.append(th.contiguous()); self.st.append(rnd(n3, 0, 1e-4))
         self.evisc = torch.zeros(n3, device=self.device, dtype=td)
         self.p = torch.zeros(n3, device=self.device, dtype=td)
         ones = np.ones(g.kcells, dtype=g.np_dtype)
         self.rhoref_h, self.rhorefh_h = ones.copy(), ones.copy()
-        self.rhoref, self.rhorefh = torch.from_numpy(ones).to(self.device), torch.from_numpy(ones).to(self.device)
-        n2 = g.shape2
-        self.surf = {k: rnd(n2, 0, 1e-2) for k in ("u_fluxbot", "u_fluxtop", "v_fluxbot", "v_fluxtop", "s_fluxbot", "s_fluxtop", "dudz", "dvdz")}
-        self.surf["dbdz"] = rnd(n2, 0, 1e-4)
-        self.surf["z0m"] = torch.full(n2, 0.1, device=self.device, dtype=td)
+        self.rhoref, self.rhorefh = torch.from_numpy(ones.copy()).to(self.device), torch.from_numpy(ones.copy()).to(self.device)
         self.thref = torch.full((g.kcells,), 300., device=self.device, dtype=td)
         self.work = torch.zeros(16, device=self.device, dtype=torch.float64)
-        # Diff_smag2::prepare_device: per-level mixing length table
+        # Diff_smag2::prepare_device: per-level mixing-length table from the host libm
         self.params = p = capi.MhhDiffParams()
         p.cs, p.tPr, p.surface_model, p.neutral, p.N2, p.th_for_N2, p.grav = 0.23, 1./3., cfg["sm"], 0, None, 0, 9.81
         p.thref = self.thref.data_ptr()
         if cfg["diff"] == DIFF_SMAG2:
             ml = np.zeros(g.kcells, dtype=g.np_dtype)
-            capi.check(self.lib.mhh_smag2_mlen0_host(g.host_struct(), p.cs, ml.ctypes.data))
+            self._ok(self.lib.mhh_smag2_mlen0_host(g.host_struct(), p.cs, ml.ctypes.data))
             self.mlen0 = torch.from_numpy(ml).to(self.device)
             p.mlen0 = self.mlen0.data_ptr()
         self.fields = self._fields()
-        # Pres::init/set_values/prepare_device
+        # Pres::init / set_values / prepare_device
         self.plan = capi.PLAN()
-        capi.check(self.lib.mhh_pres_plan_create(g.host_struct(), cfg["pres"], g.dz.ctypes.data, g.dzhi.ctypes.data, g.dzi4.ctypes.data, g.dzhi4.ctypes.data,
-                                                 self.rhoref_h.ctypes.data, self.rhorefh_h.ctypes.data, C.byref(self.plan)))
-        self._prog = (C.c_void_p * (3 + len(self.s)))(*[t.data_ptr() for t in [self.u, self.v, self.w] + self.s])
+        Gh = g.host_struct()
+        if not self.slab:
+            self._ok(self.lib.mhh_pres_plan_create(Gh, cfg["pres"], g.dz.ctypes.data, g.dzhi.ctypes.data, g.dzi4.ctypes.data, g.dzhi4.ctypes.data,
+                                                   self.rhoref_h.ctypes.data, self.rhorefh_h.ctypes.data, C.byref(self.plan)))
+        else:
+            self._ok(self.lib.mhh_pres_slab_plan_create(Gh, g.dz.ctypes.data, g.dzhi.ctypes.data, self.rhoref_h.ctypes.data, self.rhorefh_h.ctypes.data, C.byref(self.plan)))
+            nx = int(self.lib.mhh_pres_slab_xbuf_elems(self.plan))
+            self.xsend = torch.zeros(2*nx, device=self.device, dtype=td)
+            self.xrecv = torch.zeros(2*nx, device=self.device, dtype=td)
+            self._halo = {}
+        self._prog = [self.u, self.v, self.w] + self.s
         self.cyclic_prognostic()
-        torch.cuda.synchronize(self.device)
+        self.sync()
+
+    # -- plumbing -----------------------------------------------------------------------------------------
+    def _ok(self, rc):
+        capi.check(rc, self.lib)
+
+    def sync(self):
+        if self.on_gpu:
+            self.torch.cuda.synchronize(self.device)
+
+    @property
+    def stream(self):
+        if not self.on_gpu:
+            return C.c_void_p(0)
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
 
     def _fields(self):
         f = capi.MhhFields()
@@ -100,26 +165,78 @@ class HotPath:
             setattr(f, n, self.surf[n].data_ptr())
         return f
 
-    @property
-    def stream(self):
-        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+    @staticmethod
+    def _ptrs(tensors):
+        return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
-    # -- the operator calls ---------------------------------------------------------------------------
+    # -- halos ------------------------------------------------------------------------------------------------
+    def halo(self, tensors):
+        """Periodic ghost cells of 3-D fields: east-west wrap on the device, north-south wrap locally (npy == 1) or
+        by exchanging jgc rows with the ring neighbours (Boundary_cyclic::exec, src/boundary_cyclic.cxx:116-176)."""
+        arr = self._ptrs(tensors)
+        if not self.slab:
+            self._ok(self.lib.mhh_boundary_cyclic_n(self.G, arr, len(tensors), EDGE_BOTH, self.stream))
+            return
+        import torch.distributed as dist
+        self._ok(self.lib.mhh_boundary_cyclic_n(self.G, arr, len(tensors), EDGE_EW, self.stream))
+        nf = len(tensors)
+        if nf not in self._halo:
+            n = int(self.lib.mhh_halo_buffer_elems(self.G, nf))
+            self._halo[nf] = [self.torch.zeros(n, device=self.device, dtype=self.td) for _ in range(4)]
+        s_south, s_north, r_south, r_north = self._halo[nf]
+        self._ok(self.lib.mhh_halo_pack_ns(self.G, arr, nf, s_south.data_ptr(), s_north.data_ptr(), self.stream))
+        if self.npy == 1:          # both neighbours are this rank: the exchange is a local swap
+            r_south.copy_(s_north); r_north.copy_(s_south)
+            self._ok(self.lib.mhh_halo_unpack_ns(self.G, arr, nf, r_south.data_ptr(), r_north.data_ptr(), self.stream))
+            return
+        south, north = (self.rank - 1) % self.npy, (self.rank + 1) % self.npy
+        ranks = dist.get_process_group_ranks(self.group) if self.group is not None else list(range(self.npy))
+        ops = [dist.P2POp(dist.isend, s_north, ranks[north], self.group), dist.P2POp(dist.isend, s_south, ranks[south], self.group),
+               dist.P2POp(dist.irecv, r_south, ranks[south], self.group), dist.P2POp(dist.irecv, r_north, ranks[north], self.group)]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        self._ok(self.lib.mhh_halo_unpack_ns(self.G, arr, nf, r_south.data_ptr(), r_north.data_ptr(), self.stream))
+
     def cyclic_prognostic(self):
-        capi.check(self.lib.mhh_boundary_cyclic_n(self.G, self._prog, len(self._prog), EDGE_BOTH, self.stream))
+        self.halo(self._prog)
 
+    # -- the operator calls -----------------------------------------------------------------------------------
     def exec_viscosity(self):
-        capi.check(self.lib.mhh_diff_exec_viscosity(self.G, self.cfg["diff"], C.byref(self.fields), C.byref(self.params), self.stream))
+        self._ok(self.lib.mhh_diff_exec_viscosity(self.G, self.cfg["diff"], C.byref(self.fields), C.byref(self.params), self.stream))
+        if self.slab and self.cfg["diff"] == DIFF_SMAG2:
+            self.halo([self.evisc])
 
     def rhs(self):
-        capi.check(self.lib.mhh_rhs_exec(self.G, self.cfg["advec"], self.cfg["diff"], C.byref(self.fields), C.byref(self.params), self.stream))
+        self._ok(self.lib.mhh_rhs_exec(self.G, self.cfg["advec"], self.cfg["diff"], C.byref(self.fields), C.byref(self.params), self.stream))
 
     def rhs_unfused(self):
-        capi.check(self.lib.mhh_advec_exec(self.G, self.cfg["advec"], C.byref(self.fields), self.stream))
-        capi.check(self.lib.mhh_diff_exec(self.G, self.cfg["diff"], C.byref(self.fields), C.byref(self.params), self.stream))
+        self._ok(self.lib.mhh_advec_exec(self.G, self.cfg["advec"], C.byref(self.fields), self.stream))
+        self._ok(self.lib.mhh_diff_exec(self.G, self.cfg["diff"], C.byref(self.fields), C.byref(self.params), self.stream))
 
     def pres(self):
-        capi.check(self.lib.mhh_pres_exec(self.plan, self.G, C.byref(self.fields), self.dt, self.stream))
+        if not self.slab:
+            self._ok(self.lib.mhh_pres_exec(self.plan, self.G, C.byref(self.fields), self.dt, self.stream))
+            return
+        import torch.distributed as dist
+        lib, st = self.lib, self.stream
+        self.halo([self.vt])                                        # vt[j+1] at the slab edge (pres_2.cxx:181)
+        packed = lib.mhh_pres_slab_packed(self.plan)
+        self._ok(lib.mhh_pres_input_packed(self.G, 2, C.byref(self.fields), self.dt, packed, st))
+        self._ok(lib.mhh_pres_fwd_x_pack(self.plan, self.G, packed, self.xsend.data_ptr(), st))
+        self._transpose()                                                    # Transpose::exec_xy
+        self._ok(lib.mhh_pres_fwd_y_solve_bwd_y(self.plan, self.G, self.xrecv.data_ptr(), self.xsend.data_ptr(), self.stream))
+        self._transpose()                                                    # Transpose::exec_yx
+        self._ok(lib.mhh_pres_bwd_x_unpack(self.plan, self.G, self.xrecv.data_ptr(), C.byref(self.fields), self.stream))
+        self.halo([self.p])
+        self._ok(lib.mhh_pres_output_order(self.G, 2, C.byref(self.fields), self.stream))
+
+    def _transpose(self):
+        """x<->y transpose of the spectral pressure: one equal-split all-to-all (RCCL over xGMI)."""
+        if self.npy == 1:
+            self.xrecv.copy_(self.xsend)
+            return
+        import torch.distributed as dist
+        dist.all_to_all_single(self.xrecv, self.xsend, group=self.group)
 
     def step(self):
         """One full RHS + pressure evaluation (the BASELINE metric's unit of work)."""
@@ -128,26 +245,35 @@ class HotPath:
         self.rhs()
         self.pres()
 
+    # -- reductions (local max, then MAX over ranks: Master::max, src/master_parallel.cxx:233-266) --------------
+    def _allmax(self, v):
+        if self.npy == 1:
+            return v
+        import torch.distributed as dist
+        t = self.torch.tensor([v], device=self.device, dtype=self.torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return float(t.item())
+
     def divergence(self):
         out = C.c_double(0)
-        capi.check(self.lib.mhh_pres_check_divergence(self.G, self.cfg["pres"], C.byref(self.fields), self.work.data_ptr(), C.byref(out), self.stream))
-        return out.value
+        self._ok(self.lib.mhh_pres_check_divergence(self.G, self.cfg["pres"], C.byref(self.fields), self.work.data_ptr(), C.byref(out), self.stream))
+        return self._allmax(out.value)
 
     def cfl(self, dt):
         out = C.c_double(0)
-        capi.check(self.lib.mhh_advec_cfl(self.G, self.cfg["advec"], self.u.data_ptr(), self.v.data_ptr(), self.w.data_ptr(), dt, self.work.data_ptr(), C.byref(out), self.stream))
-        return out.value
+        self._ok(self.lib.mhh_advec_cfl(self.G, self.cfg["advec"], self.u.data_ptr(), self.v.data_ptr(), self.w.data_ptr(), dt, self.work.data_ptr(), C.byref(out), self.stream))
+        return self._allmax(out.value)
 
     def close(self):
         if self.plan:
-            self.lib.mhh_pres_plan_destroy(self.plan)
+            (self.lib.mhh_pres_slab_plan_destroy if self.slab else self.lib.mhh_pres_plan_destroy)(self.plan)
             self.plan = None
 
-    # algorithmic bytes per interior cell (SURVEY.md §8d / BASELINE.md §3)
+    # -- algorithmic bytes per interior cell (SURVEY.md §8d / BASELINE.md §3) -------------------------------------
     def alg_bytes_rhs(self):
         s = self.grid.np_dtype.itemsize
         F = 3 + len(self.s)
-        return (3*F)*s if self.cfg["diff"] != DIFF_SMAG2 else (F + 1 + 2*F)*s   # pass B only; evisc pass = (F+1)*s
+        return (3*F)*s if self.cfg["diff"] != DIFF_SMAG2 else (F + 1 + 2*F)*s   # smag2: pass B (tendencies); pass A below
 
     def alg_bytes_visc(self):
         s = self.grid.np_dtype.itemsize

@@ -39,7 +39,21 @@ inline void emul_fft_run(const rocfft_plan_t& P, void* in, void* out)
     for (size_t b=0; b<P.batch; ++b)
     {
         std::vector<cd> full(n0*n1);
-        if (P.type == rocfft_transform_type_real_forward)
+        if (P.type == rocfft_transform_type_complex_forward || P.type == rocfft_transform_type_complex_inverse)
+        {
+            const double sgn = (P.type == rocfft_transform_type_complex_forward) ? -1.0 : 1.0;
+            const std::complex<T>* x = static_cast<const std::complex<T>*>(in) + b*n0;
+            std::complex<T>* y = static_cast<std::complex<T>*>(out) + b*n0;
+            std::vector<cd> res(n0);
+            for (size_t k=0; k<n0; ++k)
+            {
+                cd acc = 0;
+                for (size_t j=0; j<n0; ++j) acc += cd(x[j].real(), x[j].imag()) * std::polar(1.0, sgn*2*pi*(double)((k*j) % n0)/n0);
+                res[k] = acc;
+            }
+            for (size_t k=0; k<n0; ++k) y[k] = std::complex<T>((T)res[k].real(), (T)res[k].imag());
+        }
+        else if (P.type == rocfft_transform_type_real_forward)
         {
             const T* r = static_cast<const T*>(in) + b*n0*n1;
             std::complex<T>* h = static_cast<std::complex<T>*>(out) + b*nh*n1;
@@ -72,6 +86,7 @@ inline void emul_fft_run(const rocfft_plan_t& P, void* in, void* out)
 }
 inline rocfft_status rocfft_execute(rocfft_plan p, void* in[], void* out[], rocfft_execution_info)
 {
-    if (p->prec == rocfft_precision_double) emul_fft_run<double>(*p, in[0], out[0]); else emul_fft_run<float>(*p, in[0], out[0]);
+    void* o = out ? out[0] : in[0];      // in-place plans pass no output buffer
+    if (p->prec == rocfft_precision_double) emul_fft_run<double>(*p, in[0], o); else emul_fft_run<float>(*p, in[0], o);
     return rocfft_status_success;
 }
