@@ -23,6 +23,18 @@ def _newer(src, dst):
     return (not os.path.exists(dst)) or os.path.getmtime(src) > os.path.getmtime(dst)
 
 
+def build_variant(tag, extra_flags):
+    """Experiment builds (tuning sweeps): microhh_amd/variants/libmhh_hip_<tag>.so, never loaded by default."""
+    vdir = os.path.join(HERE, "variants")
+    os.makedirs(vdir, exist_ok=True)
+    lib = os.path.join(vdir, "libmhh_hip_%s.so" % tag)
+    flags = [f for f in CFLAGS if not (f.startswith("-ffp-contract") and any(e.startswith("-ffp-contract") for e in extra_flags))]
+    cmd = [HIPCC] + flags + list(extra_flags) + ["-shared", "-o", lib] + [os.path.join(CSRC, s) for s in SOURCES] + ["-L/opt/rocm/lib", "-lrocfft", "-Wl,-rpath,/opt/rocm/lib"]
+    print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return lib
+
+
 def build(force=False, verbose=True):
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "mhh_hip.h")]
     objs, jobs = [], []

@@ -111,6 +111,10 @@ def lib():
     """The HIP library. Raises if it has not been built -- there is no fallback path."""
     global _lib
     if _lib is None:
+        path = os.environ.get("MHH_LIB") or LIB_PATH      # tuning sweeps point this at a variant build of the SAME sources
+        if path != LIB_PATH:
+            _lib = bind(C.CDLL(path))
+            return _lib
         if not os.path.exists(LIB_PATH):
             raise ImportError("%s not found: build it with `python -m microhh_amd.build` (needs hipcc); "
                               "microhh_amd has no CPU fallback" % LIB_PATH)

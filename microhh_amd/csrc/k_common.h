@@ -63,25 +63,69 @@ inline int check_grid(const mhh_grid* g)
 // ---- generic one-thread-per-cell kernel --------------------------------------------------------------
 // Block = BX x BY threads over (i, j); blockIdx.z walks the k range, so everything that depends on k
 // (metric rows, density, 2i5 face orders, wall branches) is wave-uniform.
-constexpr int BX = 64, BY = 4;
+#ifndef MHH_BX
+#define MHH_BX 64
+#define MHH_BY 4
+#endif
+constexpr int BX = MHH_BX, BY = MHH_BY;    // BX must stay a multiple of 64 (wave_reduce.h assumes BX == 64 for reductions)
+
+// Block -> tile mapping, XCD-aware. MI355X has 8 XCDs with a private 4 MiB L2 each and workgroups are dealt
+// round-robin over them (block L runs on XCD L % 8: observed placement, used for speed only -- any other
+// placement gives the same results). A stencil sweep re-reads every plane 3..7 times in k and every row 3..7
+// times in j; dealing neighbouring tiles to different XCDs makes each L2 hold the whole working set and miss
+// (measured: 6x the algorithmic HBM bytes on the fused 2i5+smag2 pass at 512^3). So each XCD gets whole
+// "strips" of SR block-rows (all i), and walks a strip plane by plane in k before taking its next strip:
+// the live working set of an XCD is (rows of a strip + halo) x (planes of the stencil + planes in flight).
+struct Tiling { int nbx, nby, nk, sr, ns; };
+#ifndef MHH_STRIP_ROWS
+#define MHH_STRIP_ROWS 16          // grid rows per strip (tuned on MI355X)
+#endif
+
+__device__ __forceinline__ bool decode_tile(const Tiling& t, unsigned L, int& bx, int& by, int& kz)
+{
+    const int xcd = L & 7u;
+    const unsigned tt = L >> 3;
+    const unsigned per_strip = (unsigned)t.sr * t.nbx * t.nk;
+    const unsigned round = tt / per_strip;
+    unsigned r = tt - round * per_strip;
+    const int strip = (int)round * 8 + xcd;
+    if (strip >= t.ns) return false;
+    const unsigned per_plane = (unsigned)t.sr * t.nbx;
+    kz = (int)(r / per_plane); r -= (unsigned)kz * per_plane;
+    const int byl = (int)(r / t.nbx);
+    bx = (int)(r - (unsigned)byl * t.nbx);
+    by = strip * t.sr + byl;
+    return by < t.nby;
+}
 
 template<class Op>
-__global__ void __launch_bounds__(BX*BY) cell_kernel(const Op op, int i0, int i1, int j0, int j1, int k0, int jj, int kk)
+__global__ void __launch_bounds__(BX*BY) cell_kernel(const Op op, const Tiling t, int i0, int i1, int j0, int j1, int k0, int jj, int kk)
 {
-    const int i = i0 + blockIdx.x*BX + threadIdx.x;
-    const int j = j0 + blockIdx.y*BY + threadIdx.y;
-    const int k = k0 + blockIdx.z;
+    int bx, by, kz;
+    if (!decode_tile(t, blockIdx.x, bx, by, kz)) return;
+    const int i = i0 + bx*BX + threadIdx.x;
+    const int j = j0 + by*BY + threadIdx.y;
+    const int k = k0 + kz;
     if (i < i1 && j < j1)
         op(i, j, k, i + j*jj + k*kk);
 }
+
+inline Tiling make_tiling(int ni, int nj, int nk)
+{
+    Tiling t;
+    t.nbx = (ni + BX-1)/BX; t.nby = (nj + BY-1)/BY; t.nk = nk;
+    t.sr = (MHH_STRIP_ROWS + BY-1)/BY; if (t.sr < 1) t.sr = 1;
+    t.ns = (t.nby + t.sr-1)/t.sr;
+    return t;
+}
+inline unsigned tiling_blocks(const Tiling& t) { return 8u * (unsigned)((t.ns + 7)/8) * (unsigned)t.sr * t.nbx * t.nk; }
 
 template<class Op>
 inline int launch_cells(hipStream_t st, const Op& op, int i0, int i1, int j0, int j1, int k0, int k1, int jj, int kk)
 {
     if (k1 <= k0 || i1 <= i0 || j1 <= j0) return MHH_OK;
-    dim3 block(BX, BY, 1);
-    dim3 grid((i1-i0 + BX-1)/BX, (j1-j0 + BY-1)/BY, k1-k0);
-    hipLaunchKernelGGL(cell_kernel<Op>, grid, block, 0, st, op, i0, i1, j0, j1, k0, jj, kk);
+    const Tiling t = make_tiling(i1-i0, j1-j0, k1-k0);
+    hipLaunchKernelGGL(cell_kernel<Op>, dim3(tiling_blocks(t)), dim3(BX, BY, 1), 0, st, op, t, i0, i1, j0, j1, k0, jj, kk);
     MHH_LAUNCH_CHECK();
     return MHH_OK;
 }

@@ -1,3 +1,9 @@
 #include <hip/hip_runtime.h>
 thread_local uint3e blockIdx, threadIdx;
 thread_local dim3 blockDim, gridDim;
+EmulState g_emul;
+extern "C" void emul_fiber_entry()
+{
+    g_emul.body();
+    g_emul.cur->done = true;     // returning switches to uc_link = the scheduler
+}

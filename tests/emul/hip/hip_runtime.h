@@ -33,18 +33,71 @@ inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? 0 : 2; }
 inline hipError_t hipFree(void* p) { free(p); return 0; }
 
-// Threads of a block run in REVERSE order so that thread (0,0) goes last (see tests/emul/wave_reduce.h).
+// Execution model: every simulated thread of a block is a fiber (ucontext). A fiber runs until it finishes or
+// reaches __syncthreads(), which yields to the scheduler; the scheduler resumes the block's fibers round-robin,
+// so all of them arrive at a barrier before any leaves it. Fibers are started in REVERSE thread order so that
+// thread (0,0) goes last within each phase (tests/emul/wave_reduce.h relies on that). Blocks run one at a time,
+// so `__shared__` (= static) storage is naturally per block.
+#include <ucontext.h>
+#include <vector>
+#include <functional>
+struct EmulFiber { ucontext_t ctx; std::vector<char> stack; bool done = false; uint3e tid; };
+struct EmulState { ucontext_t sched; EmulFiber* cur = nullptr; std::function<void()> body; };
+extern EmulState g_emul;
+extern "C" void emul_fiber_entry();
+struct EmulNeedsFibers {};
+// A kernel is first run with plain calls (fast). The first __syncthreads() met in that mode aborts the block,
+// and the launch site switches to fiber mode for good (work done before the first barrier is simply redone).
+inline void __syncthreads() { if (!g_emul.cur) throw EmulNeedsFibers(); swapcontext(&g_emul.cur->ctx, &g_emul.sched); }
+
 template<class F>
 inline void emul_launch(dim3 grid, dim3 block, F&& body)
 {
     gridDim = grid; blockDim = block;
+    const size_t nthreads = (size_t)block.x*block.y*block.z;
+    static std::vector<EmulFiber> fibers;
+    if (fibers.size() < nthreads) fibers.resize(nthreads);
+    g_emul.body = [&]{ body(); };
+    static bool need_fibers = false;          // one flag per launch site (this template is instantiated per kernel lambda)
     for (unsigned bz=0; bz<grid.z; ++bz) for (unsigned by=0; by<grid.y; ++by) for (unsigned bx=0; bx<grid.x; ++bx)
     {
         blockIdx = {bx, by, bz};
+        if (!need_fibers)
+        {
+            g_emul.cur = nullptr;
+            try
+            {
+                for (int tz=(int)block.z-1; tz>=0; --tz) for (int ty=(int)block.y-1; ty>=0; --ty) for (int tx=(int)block.x-1; tx>=0; --tx)
+                {
+                    threadIdx = {(unsigned)tx, (unsigned)ty, (unsigned)tz};
+                    body();
+                }
+                continue;
+            }
+            catch (const EmulNeedsFibers&) { need_fibers = true; }
+        }
+        size_t n = 0;
         for (int tz=(int)block.z-1; tz>=0; --tz) for (int ty=(int)block.y-1; ty>=0; --ty) for (int tx=(int)block.x-1; tx>=0; --tx)
         {
-            threadIdx = {(unsigned)tx, (unsigned)ty, (unsigned)tz};
-            body();
+            EmulFiber& f = fibers[n++];
+            if (f.stack.empty()) f.stack.resize(256*1024);
+            f.done = false; f.tid = {(unsigned)tx, (unsigned)ty, (unsigned)tz};
+            getcontext(&f.ctx);
+            f.ctx.uc_stack.ss_sp = f.stack.data(); f.ctx.uc_stack.ss_size = f.stack.size(); f.ctx.uc_link = &g_emul.sched;
+            makecontext(&f.ctx, (void(*)())emul_fiber_entry, 0);
+        }
+        bool alive = true;
+        while (alive)
+        {
+            alive = false;
+            for (size_t m=0; m<nthreads; ++m)
+            {
+                EmulFiber& f = fibers[m];
+                if (f.done) continue;
+                g_emul.cur = &f; threadIdx = f.tid;
+                swapcontext(&g_emul.sched, &f.ctx);
+                if (!f.done) alive = true;
+            }
         }
     }
 }
