@@ -1,0 +1,395 @@
+// k_march.hip -- the flagship kernel: advec_2i5 + diff_smag2 for u, v, w and one scalar in ONE pass, as a
+// k-marching, LDS-staged, register-pipelined stencil sweep for gfx950.
+//
+// Why this shape (numbers: profiles/r1b_sweep_xcd_tiling.md): the one-thread-per-cell version issues ~180 vector
+// loads per cell through the 64 B/clk L1 and is bound by that pipe, not by HBM or VALU. Here a 64 x NJ block of
+// threads owns a column tile and walks up in k:
+//   * the plane being updated and its two neighbours live in LDS with their halos (u, v, w: +-3; evisc: +-1),
+//     loaded once per block (x1.9..2.7 halo amplification instead of x20 re-reads), read back with ds_read_b64;
+//   * each thread keeps the 7-deep k-window of its own column of u, v, w, s in registers;
+//   * vertical face fluxes (advective centred/upwind parts and the Smagorinsky stress) are computed once, on the
+//     top face, and carried to the next level as its bottom face -- identical operands, identical rounding, so
+//     the result is still bit-identical to the reference CPU path (src/advec_2i5.cxx, src/diff_smag2.cxx);
+//   * the next plane is prefetched into registers while the current one is being computed (loads in flight
+//     across the whole compute phase), then written to the LDS ring between two barriers.
+// Accumulation order per tendency is the reference's: t += advec_horizontal; t += advec_vertical; t += diffusion.
+#include "k_common.h"
+
+using namespace mhh;
+
+namespace
+{
+template<class TF> __device__ __forceinline__ TF win_cen(const TF (&w)[7], int order)     // window index 3 = level k; face k+1/2
+{
+    if (order == 2) return i2(w[3], w[4]);
+    if (order == 4) return i4ws(w[2], w[3], w[4], w[5]);
+    return i6(w[1], w[2], w[3], w[4], w[5], w[6]);
+}
+template<class TF> __device__ __forceinline__ TF win_upw(const TF (&w)[7], int order)
+{
+    if (order == 4) return i3ws(w[2], w[3], w[4], w[5]);
+    return i5(w[1], w[2], w[3], w[4], w[5], w[6]);
+}
+// vertical advective increment from the face products T = rt*w_t*I_t, B = rb*w_b*I_b, Gt = rt*|w_t|*D_t, Gb likewise
+// x / rc with the wave-uniform shortcut for rc == 1 (Boussinesq base state): x / 1 is x, bit for bit, and an
+// fp64 division is ~12 VALU instructions that this kernel would otherwise issue ~12 times per cell.
+template<class TF> __device__ __forceinline__ TF div_rho(TF x, TF rc, bool one) { return one ? x : x / rc; }
+
+template<class TF> __device__ __forceinline__ TF vert_combine(int ot, int ob, TF T, TF B, TF Gt, TF Gb, TF rc, bool one, TF dz)
+{
+    TF cen;
+    if (ob == 0)      cen = - div_rho( T, rc, one ) * dz;
+    else if (ot == 0) cen = - div_rho( -B, rc, one ) * dz;
+    else              cen = - div_rho( T - B, rc, one ) * dz;
+    const bool ut = (ot >= 4), ub = (ob >= 4);
+    if (ut && ub) return cen + div_rho( Gt - Gb, rc, one ) * dz;
+    if (ut)       return cen + div_rho( Gt, rc, one ) * dz;
+    if (ub)       return cen - div_rho( Gb, rc, one ) * dz;
+    return cen;
+}
+template<class TF> __device__ __forceinline__ void shift(TF (&w)[7], TF nw)
+{
+    w[0] = w[1]; w[1] = w[2]; w[2] = w[3]; w[3] = w[4]; w[4] = w[5]; w[5] = w[6]; w[6] = nw;
+}
+
+template<class TF> struct MarchFields
+{
+    const TF* __restrict__ u; const TF* __restrict__ v; const TF* __restrict__ w; const TF* __restrict__ s; const TF* __restrict__ ev;
+    TF* __restrict__ ut; TF* __restrict__ vt; TF* __restrict__ wt; TF* __restrict__ st;
+    const TF* __restrict__ rhoref; const TF* __restrict__ rhorefh;
+    const TF* __restrict__ ufb; const TF* __restrict__ uft; const TF* __restrict__ vfb; const TF* __restrict__ vft;
+    const TF* __restrict__ sfb; const TF* __restrict__ sft;
+    TF visc, svisc, tPr; int sm;
+};
+
+struct MarchTiling { int nbx, nby, nkc, sr, ns, kc; };
+
+__device__ __forceinline__ bool decode_march(const MarchTiling& t, unsigned L, int& bx, int& by, int& kc)
+{
+    // same XCD-aware strip order as decode_tile (k_common.h), with k-chunks in place of k-planes
+    const int xcd = L & 7u;
+    const unsigned tt = L >> 3;
+    const unsigned per_strip = (unsigned)t.sr * t.nbx * t.nkc;
+    const unsigned round = tt / per_strip;
+    unsigned r = tt - round * per_strip;
+    const int strip = (int)round * 8 + xcd;
+    if (strip >= t.ns) return false;
+    const unsigned per_chunk = (unsigned)t.sr * t.nbx;
+    kc = (int)(r / per_chunk); r -= (unsigned)kc * per_chunk;
+    const int byl = (int)(r / t.nbx);
+    bx = (int)(r - (unsigned)byl * t.nbx);
+    by = strip * t.sr + byl;
+    return by < t.nby;
+}
+
+template<class TF, int NJ, bool HAS_S>
+__global__ void __launch_bounds__(64*NJ, 2) rhs25_march_kernel(const GridDev<TF> g, const MarchFields<TF> f, const MarchTiling mt)
+{
+    constexpr int TI = 70, TJ = NJ + 6, TE = 66, TJE = NJ + 2, NT = 64*NJ;
+    constexpr int NTILE = TI*TJ, NETILE = TE*TJE;
+    constexpr int NLD = (NTILE + NT - 1) / NT, NLDE = (NETILE + NT - 1) / NT;
+    __shared__ TF U[3][NTILE];
+    __shared__ TF V[3][NTILE];
+    __shared__ TF W[3][NTILE];
+    __shared__ TF S[HAS_S ? 2 : 1][HAS_S ? NTILE : 1];
+    __shared__ TF E[3][NETILE];
+
+    int bx, by, kcn;
+    if (!decode_march(mt, blockIdx.x, bx, by, kcn)) return;        // whole block leaves together: no barrier hazard
+    const int jj = g.icells, kk = g.ijcells;
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty*64 + tx;
+    const int i0 = g.istart + bx*64, j0 = g.jstart + by*NJ;
+    const int kb = g.kstart + kcn*mt.kc;
+    const int ke = (kb + mt.kc < g.kend) ? kb + mt.kc : g.kend;
+    const int i = i0 + tx, j = j0 + ty;
+    const bool active = (i < g.iend) && (j < g.jend);
+    const int ci = (i < g.iend) ? i : g.iend-1, cj = (j < g.jend) ? j : g.jend-1;   // clamped column for the window loads
+    const int col = ci + cj*jj;
+    const int ij = col;
+    const int l = (ty+3)*TI + (tx+3), le = (ty+1)*TE + (tx+1);
+
+    // ---- tile movers: element e = tid + n*NT of the (TJ x TI) tile; global offsets within a plane computed once -----
+    int off[NLD], offe[NLDE];
+    bool okt[NLD], oke[NLDE];
+#pragma unroll
+    for (int n=0; n<NLD; ++n)
+    {
+        const int e = tid + n*NT;
+        const int tj = e / TI, ti = e - tj*TI;
+        const int gi = i0 - 3 + ti, gj = j0 - 3 + tj;
+        okt[n] = (e < NTILE) && (gi < g.icells) && (gj < g.jcells);
+        off[n] = okt[n] ? gi + gj*jj : 0;
+    }
+#pragma unroll
+    for (int n=0; n<NLDE; ++n)
+    {
+        const int e = tid + n*NT;
+        const int tj = e / TE, ti = e - tj*TE;
+        const int gi = i0 - 1 + ti, gj = j0 - 1 + tj;
+        oke[n] = (e < NETILE) && (gi < g.icells) && (gj < g.jcells);
+        offe[n] = oke[n] ? gi + gj*jj : 0;
+    }
+    auto ld_tile = [&](const TF* __restrict__ fld, int kp, TF (&r)[NLD])
+    {
+        const bool kok = (kp >= 0) && (kp < g.kcells);
+        const TF* __restrict__ pl = fld + (kok ? (size_t)kp*kk : 0);
+#pragma unroll
+        for (int n=0; n<NLD; ++n) r[n] = (kok && okt[n]) ? pl[off[n]] : TF(0);
+    };
+    auto st_tile = [&](TF* __restrict__ lds, const TF (&r)[NLD])
+    {
+#pragma unroll
+        for (int n=0; n<NLD; ++n) { const int e = tid + n*NT; if (n+1 < NLD || e < NTILE) lds[e] = r[n]; }
+    };
+    auto ld_etile = [&](int kp, TF (&r)[NLDE])
+    {
+        const bool kok = (kp >= 0) && (kp < g.kcells);
+        const TF* __restrict__ pl = f.ev + (kok ? (size_t)kp*kk : 0);
+#pragma unroll
+        for (int n=0; n<NLDE; ++n) r[n] = (kok && oke[n]) ? pl[offe[n]] : TF(0);
+    };
+    auto st_etile = [&](TF* __restrict__ lds, const TF (&r)[NLDE])
+    {
+#pragma unroll
+        for (int n=0; n<NLDE; ++n) { const int e = tid + n*NT; if (n+1 < NLDE || e < NETILE) lds[e] = r[n]; }
+    };
+    auto colval = [&](const TF* __restrict__ fld, int kp) -> TF
+    {
+        return (kp >= 0 && kp < g.kcells) ? fld[col + kp*kk] : TF(0);
+    };
+    auto slot = [](int p) { return (p + 3) % 3; };
+
+    // ---- prologue: planes ks-1, ks, ks+1 into the ring, scalar plane ks, windows centred on ks ------------------
+    const int ks = kb - 1;                 // warm-up level: only top-face quantities are formed there
+    {
+        TF r[NLD]; TF re[NLDE];
+        for (int p = ks-1; p <= ks+1; ++p)
+        {
+            ld_tile(f.u, p, r); st_tile(U[slot(p)], r);
+            ld_tile(f.v, p, r); st_tile(V[slot(p)], r);
+            ld_tile(f.w, p, r); st_tile(W[slot(p)], r);
+            ld_etile(p, re);    st_etile(E[slot(p)], re);
+        }
+        if (HAS_S) { ld_tile(f.s, ks, r); st_tile(S[ks & 1], r); }
+    }
+    TF uw[7], vw[7], ww[7], sw[7];
+#pragma unroll
+    for (int n=0; n<7; ++n)
+    {
+        uw[n] = colval(f.u, ks-3+n); vw[n] = colval(f.v, ks-3+n); ww[n] = colval(f.w, ks-3+n);
+        sw[n] = HAS_S ? colval(f.s, ks-3+n) : TF(0);
+    }
+    __syncthreads();
+
+    // carried bottom-face products: advective centred (T) and upwind (G) parts, diffusive flux (D)
+    TF cTu = 0, cGu = 0, cDu = 0, cTv = 0, cGv = 0, cDv = 0, cTw = 0, cGw = 0, cDw = 0, cTs = 0, cGs = 0, cDs = 0;
+
+    const TF dxi = g.dxi_t, dyi = g.dyi_t;          // advection spelling TF(1.)/dx
+    const TF dxd = g.dxi_d, dyd = g.dyi_d;          // diffusion spelling TF(1./dx)
+    const TF visc = f.visc;
+
+    for (int k = ks; k < ke; ++k)
+    {
+        // ---- prefetch for the next level: plane k+2 of u, v, w, evisc; plane k+1 of s; window value k+4 ---------
+        TF pu[NLD], pv[NLD], pw[NLD], ps[NLD], pe[NLDE];
+        const bool more = (k + 1 < ke);
+        if (more)
+        {
+            ld_tile(f.u, k+2, pu); ld_tile(f.v, k+2, pv); ld_tile(f.w, k+2, pw); ld_etile(k+2, pe);
+            if (HAS_S) ld_tile(f.s, k+1, ps);
+        }
+        const TF nu = more ? colval(f.u, k+4) : TF(0), nv = more ? colval(f.v, k+4) : TF(0), nw = more ? colval(f.w, k+4) : TF(0);
+        const TF ns = (more && HAS_S) ? colval(f.s, k+4) : TF(0);
+
+        const TF* __restrict__ uk = U[slot(k)] + l;  const TF* __restrict__ ukm = U[slot(k-1)] + l;
+        const TF* __restrict__ vk = V[slot(k)] + l;  const TF* __restrict__ vkm = V[slot(k-1)] + l;
+        const TF* __restrict__ wk = W[slot(k)] + l;  const TF* __restrict__ wkp = W[slot(k+1)] + l;
+        const TF* __restrict__ sk = S[HAS_S ? (k & 1) : 0] + (HAS_S ? l : 0);
+        const TF* __restrict__ ek = E[slot(k)] + le; const TF* __restrict__ ekm = E[slot(k-1)] + le; const TF* __restrict__ ekp = E[slot(k+1)] + le;
+
+        // per-level coefficients (wave-uniform)
+        const TF rhkp = f.rhorefh[k+1], rhk = f.rhorefh[k], rk = f.rhoref[k];
+        const TF dzi = g.dzi[k], dzhi = g.dzhi[k], dzhip = g.dzhi[k+1];
+        const bool rk1 = (rk == TF(1.)), rhk1 = (rhk == TF(1.));
+        const int otc = order_face_c(k+1, g.kstart, g.kend);
+        const int obc = order_face_c(k, g.kstart, g.kend);
+        const bool wlev = (k >= g.kstart);                       // the w equation's "faces" are cell centres kstart..kend-1
+        const int otw = wlev ? order_face_w(k, g.kstart, g.kend) : 0;
+        const int obw = (k-1 >= g.kstart) ? order_face_w(k-1, g.kstart, g.kend) : 0;
+        // surface model: the lowest / highest level takes the prescribed flux instead of the resolved one
+        const bool fb = f.sm && (k == g.kstart), ft = f.sm && (k == g.kend-1);
+        const bool need_dtop = !(ft) && (k < g.kend-1 || !f.sm) && (k+1 <= g.kend);   // top diffusive flux of level k is used by k or k+1
+
+        // ---- top-face quantities of level k --------------------------------------------------------------------
+        TF Tu = 0, Gu = 0, Tv = 0, Gv = 0, Tw = 0, Gw = 0, Ts = 0, Gs = 0;
+        if (otc != 0)
+        {
+            const TF wtu = i2(wkp[-1], wkp[0]);
+            const TF wtv = i2(wkp[-TI], wkp[0]);
+            Tu = rhkp * wtu * win_cen(uw, otc);
+            Tv = rhkp * wtv * win_cen(vw, otc);
+            if (otc >= 4) { Gu = rhkp * tabs(wtu) * win_upw(uw, otc); Gv = rhkp * tabs(wtv) * win_upw(vw, otc); }
+            if (HAS_S)
+            {
+                Ts = rhkp * ww[4] * win_cen(sw, otc);
+                if (otc >= 4) Gs = rhkp * tabs(ww[4]) * win_upw(sw, otc);
+            }
+        }
+        if (wlev)
+        {
+            const TF wtw = i2(ww[3], ww[4]);
+            Tw = rk * wtw * win_cen(ww, otw);
+            if (otw >= 4) Gw = rk * tabs(wtw) * win_upw(ww, otw);
+        }
+        TF Du = 0, Dv = 0, Dw = 0, Ds = 0;
+        if (need_dtop)
+        {
+            const TF etu = TF(0.25)*(ek[-1] + ek[0] + ekp[-1] + ekp[0]) + visc;
+            Du = rhkp * etu*((uw[4]-uw[3])*dzhip + (wkp[0]-wkp[-1])*dxd);
+            const TF etv = TF(0.25)*(ek[-TE] + ek[0] + ekp[-TE] + ekp[0]) + visc;
+            Dv = rhkp * etv*((vw[4]-vw[3])*dzhip + (wkp[0]-wkp[-TI])*dyd);
+            if (HAS_S)
+            {
+                const TF ets = TF(0.5)*(ek[0]+ekp[0])/f.tPr + f.svisc;
+                Ds = rhkp * ets*(sw[4]-sw[3])*dzhip;
+            }
+        }
+        if (wlev)
+        {
+            const TF etw = ek[0] + visc;
+            Dw = rk * etw*(ww[4]-ww[3])*dzi;
+        }
+
+        // ---- update the tendencies of level k ----------------------------------------------------------------
+        if (k >= kb && active)
+        {
+            const int c = col + k*kk;
+            {   // u
+                const TF ue = i2(uk[0], uk[1]), uwf = i2(uk[-1], uk[0]);
+                const TF vn = i2(vk[TI-1], vk[TI]), vs = i2(vk[-1], vk[0]);
+                TF t = f.ut[c];
+                t += advec25_hor(uk, 0, TI, ue, uwf, vn, vs, dxi, dyi);
+                t += vert_combine(otc, obc, Tu, cTu, Gu, cGu, rk, rk1, dzi);
+                const TF ee = ek[0] + visc, ew = ek[-1] + visc;
+                const TF en = TF(0.25)*(ek[-1   ] + ek[0  ] + ek[-1+TE] + ek[TE]) + visc;
+                const TF es = TF(0.25)*(ek[-1-TE] + ek[-TE] + ek[-1   ] + ek[0 ]) + visc;
+                const TF hor = + ( ee*(uk[1]-uk[0])*dxd - ew*(uk[0]-uk[-1])*dxd ) * TF(2.)*dxd
+                               + ( en*((uk[TI]-uk[0  ])*dyd + (vk[TI]-vk[TI-1])*dxd)
+                                 - es*((uk[0 ]-uk[-TI])*dyd + (vk[0 ]-vk[-1  ])*dxd) ) * dyd;
+                TF ver;
+                if (fb)      ver = div_rho( Du + rhk * f.ufb[ij], rk, rk1 ) * dzi;
+                else if (ft) ver = div_rho( - rhkp * f.uft[ij] - cDu, rk, rk1 ) * dzi;
+                else         ver = div_rho( Du - cDu, rk, rk1 ) * dzi;
+                t += hor + ver;
+                f.ut[c] = t;
+            }
+            {   // v
+                const TF ue = i2(uk[1-TI], uk[1]), uwf = i2(uk[-TI], uk[0]);
+                const TF vn = i2(vk[0], vk[TI]), vs = i2(vk[-TI], vk[0]);
+                TF t = f.vt[c];
+                t += advec25_hor(vk, 0, TI, ue, uwf, vn, vs, dxi, dyi);
+                t += vert_combine(otc, obc, Tv, cTv, Gv, cGv, rk, rk1, dzi);
+                const TF ee = TF(0.25)*(ek[-TE  ] + ek[0 ] + ek[1-TE] + ek[1]) + visc;
+                const TF ew = TF(0.25)*(ek[-1-TE] + ek[-1] + ek[-TE ] + ek[0]) + visc;
+                const TF en = ek[0] + visc, es = ek[-TE] + visc;
+                const TF hor = + ( ee*((vk[1]-vk[0 ])*dxd + (uk[1]-uk[1-TI])*dyd)
+                                 - ew*((vk[0]-vk[-1])*dxd + (uk[0]-uk[-TI ])*dyd) ) * dxd
+                               + ( en*(vk[TI]-vk[0])*dyd - es*(vk[0]-vk[-TI])*dyd ) * TF(2.)*dyd;
+                TF ver;
+                if (fb)      ver = div_rho( Dv + rhk * f.vfb[ij], rk, rk1 ) * dzi;
+                else if (ft) ver = div_rho( - rhkp * f.vft[ij] - cDv, rk, rk1 ) * dzi;
+                else         ver = div_rho( Dv - cDv, rk, rk1 ) * dzi;
+                t += hor + ver;
+                f.vt[c] = t;
+            }
+            if (k > g.kstart)
+            {   // w
+                const TF rkm = f.rhoref[k-1];
+                const TF ue = i2(ukm[1], uk[1]), uwf = i2(ukm[0], uk[0]);
+                const TF vn = i2(vkm[TI], vk[TI]), vs = i2(vkm[0], vk[0]);
+                TF t = f.wt[c];
+                t += advec25_hor(wk, 0, TI, ue, uwf, vn, vs, dxi, dyi);
+                t += vert_combine(otw, obw, Tw, cTw, Gw, cGw, rhk, rhk1, dzhi);
+                (void)rkm;
+                const TF ee = TF(0.25)*(ekm[0  ] + ek[0  ] + ekm[1 ] + ek[1 ]) + visc;
+                const TF ew = TF(0.25)*(ekm[-1 ] + ek[-1 ] + ekm[0 ] + ek[0 ]) + visc;
+                const TF en = TF(0.25)*(ekm[0  ] + ek[0  ] + ekm[TE] + ek[TE]) + visc;
+                const TF es = TF(0.25)*(ekm[-TE] + ek[-TE] + ekm[0 ] + ek[0 ]) + visc;
+                t += + ( ee*((wk[1 ]-wk[0  ])*dxd + (uk[1 ]-ukm[1 ])*dzhi)
+                       - ew*((wk[0 ]-wk[-1 ])*dxd + (uk[0 ]-ukm[0 ])*dzhi) ) * dxd
+                     + ( en*((wk[TI]-wk[0  ])*dyd + (vk[TI]-vkm[TI])*dzhi)
+                       - es*((wk[0 ]-wk[-TI])*dyd + (vk[0 ]-vkm[0 ])*dzhi) ) * dyd
+                     + div_rho( Dw - cDw, rhk, rhk1 ) * TF(2.)*dzhi;
+                f.wt[c] = t;
+            }
+            if (HAS_S)
+            {   // scalar
+                TF t = f.st[c];
+                t += advec25_hor(sk, 0, TI, uk[1], uk[0], vk[TI], vk[0], dxi, dyi);
+                t += vert_combine(otc, obc, Ts, cTs, Gs, cGs, rk, rk1, dzi);
+                const TF ee = TF(0.5)*(ek[0  ]+ek[1 ])/f.tPr + f.svisc;
+                const TF ew = TF(0.5)*(ek[-1 ]+ek[0 ])/f.tPr + f.svisc;
+                const TF en = TF(0.5)*(ek[0  ]+ek[TE])/f.tPr + f.svisc;
+                const TF es = TF(0.5)*(ek[-TE]+ek[0 ])/f.tPr + f.svisc;
+                const TF hor = + ( ee*(sk[1 ]-sk[0]) - ew*(sk[0]-sk[-1 ]) ) * g.dxidxi_d
+                               + ( en*(sk[TI]-sk[0]) - es*(sk[0]-sk[-TI]) ) * g.dyidyi_d;
+                TF ver;
+                if (fb)      ver = div_rho( Ds + rhk * f.sfb[ij], rk, rk1 ) * dzi;
+                else if (ft) ver = div_rho( -rhkp * f.sft[ij] - cDs, rk, rk1 ) * dzi;
+                else         ver = div_rho( Ds - cDs, rk, rk1 ) * dzi;
+                t += hor + ver;
+                f.st[c] = t;
+            }
+        }
+        // ---- carry the top faces down, rotate the ring, shift the windows --------------------------------------
+        cTu = Tu; cGu = Gu; cDu = Du; cTv = Tv; cGv = Gv; cDv = Dv; cTw = Tw; cGw = Gw; cDw = Dw; cTs = Ts; cGs = Gs; cDs = Ds;
+        if (more)
+        {
+            __syncthreads();                                   // everyone is done reading plane k-1 (and scalar plane k)
+            st_tile(U[slot(k+2)], pu); st_tile(V[slot(k+2)], pv); st_tile(W[slot(k+2)], pw); st_etile(E[slot(k+2)], pe);
+            if (HAS_S) st_tile(S[(k+1) & 1], ps);
+            __syncthreads();
+            shift(uw, nu); shift(vw, nv); shift(ww, nw); shift(sw, ns);
+        }
+    }
+}
+
+template<class TF>
+int march_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, hipStream_t st)
+{
+#ifndef MHH_MARCH_NJ
+#define MHH_MARCH_NJ 4
+#endif
+    constexpr int NJ = MHH_MARCH_NJ;
+    const GridDev<TF> gd = make_grid<TF>(g);
+    MarchFields<TF> mf;
+    mf.u = cp<TF>(f->u); mf.v = cp<TF>(f->v); mf.w = cp<TF>(f->w); mf.ev = cp<TF>(f->evisc);
+    mf.ut = mp<TF>(f->ut); mf.vt = mp<TF>(f->vt); mf.wt = mp<TF>(f->wt);
+    const bool has_s = f->nscalars >= 1;
+    mf.s = has_s ? cp<TF>(f->s[0]) : nullptr; mf.st = has_s ? mp<TF>(f->st[0]) : nullptr;
+    mf.rhoref = cp<TF>(f->rhoref); mf.rhorefh = cp<TF>(f->rhorefh);
+    mf.ufb = cp<TF>(f->u_fluxbot); mf.uft = cp<TF>(f->u_fluxtop); mf.vfb = cp<TF>(f->v_fluxbot); mf.vft = cp<TF>(f->v_fluxtop);
+    mf.sfb = has_s ? cp<TF>(f->s_fluxbot[0]) : nullptr; mf.sft = has_s ? cp<TF>(f->s_fluxtop[0]) : nullptr;
+    mf.visc = TF(f->visc); mf.svisc = has_s ? TF(f->svisc[0]) : TF(0); mf.tPr = TF(p->tPr); mf.sm = p->surface_model;
+    MarchTiling t;
+    t.nbx = (g->imax + 63)/64; t.nby = (g->jmax + NJ-1)/NJ;
+#ifndef MHH_MARCH_KC
+#define MHH_MARCH_KC 128
+#endif
+    t.kc = MHH_MARCH_KC; t.nkc = (g->kmax + t.kc - 1)/t.kc;
+    t.sr = (MHH_STRIP_ROWS + NJ-1)/NJ; if (t.sr < 1) t.sr = 1;
+    t.ns = (t.nby + t.sr-1)/t.sr;
+    const unsigned nblocks = 8u * (unsigned)((t.ns + 7)/8) * (unsigned)t.sr * t.nbx * t.nkc;
+    if (has_s) hipLaunchKernelGGL((rhs25_march_kernel<TF, NJ, true>),  dim3(nblocks), dim3(64, NJ), 0, st, gd, mf, t);
+    else       hipLaunchKernelGGL((rhs25_march_kernel<TF, NJ, false>), dim3(nblocks), dim3(64, NJ), 0, st, gd, mf, t);
+    MHH_LAUNCH_CHECK();
+    return MHH_OK;
+}
+} // namespace
+
+// entry used by mhh_rhs_exec for the (advec_2i5, diff_smag2) pair: u, v, w and scalar 0 (inputs validated by the caller)
+int mhh_rhs25_march(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, void* stream)
+{
+    if (g->dtype == MHH_F64) return march_launch<double>(g, f, p, as_stream(stream));
+    return march_launch<float>(g, f, p, as_stream(stream));
+}

@@ -1,9 +1,12 @@
 // k_rhs.hip -- operator-level entry points: Diff::exec_viscosity, Diff::exec, the fused advec+diff RHS pass,
 // and the max-reductions behind get_cfl / get_dn / check_divergence. gfx950 only.
+#include <cstdlib>
 #include "k_common.h"
 #include <wave_reduce.h>   // angle form: the CPU emulation build (tests/emul) overrides it by include path
 
 using namespace mhh;
+
+int mhh_rhs25_march(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, void* stream);   // k_march.hip
 
 // =======================================================================================================
 // Max reductions (calc_cfl / calc_dnmul / calc_divergence + Master::max). All integrands are |.| >= 0, so the
@@ -382,6 +385,19 @@ MHH_API int mhh_rhs_exec(const mhh_grid* g, int advec_scheme, int diff_scheme, c
         {
             MHH_REQUIRE(f->u_fluxbot && f->u_fluxtop && f->v_fluxbot && f->v_fluxtop, "surface fluxes");
             for (int n=0; n<f->nscalars; ++n) MHH_REQUIRE(f->s_fluxbot[n] && f->s_fluxtop[n], "scalar surface fluxes");
+        }
+        // default: the k-marching LDS kernel (k_march.hip) for u, v, w and scalar 0; further scalars take the
+        // per-field kernels. MHH_RHS25_IMPL=cell selects the one-thread-per-cell fused kernel (A/B measurements).
+        static const bool use_cell = [] { const char* e = getenv("MHH_RHS25_IMPL"); return e && !strcmp(e, "cell"); }();
+        if (!use_cell)
+        {
+            if (int e = mhh_rhs25_march(g, f, p, stream)) return e;
+            for (int n=1; n<f->nscalars; ++n)
+            {
+                if (int e = mhh_advec_s(g, MHH_ADVEC_2I5, f->st[n], f->s[n], f->u, f->v, f->w, f->rhoref, f->rhorefh, stream)) return e;
+                if (int e = mhh_smag2_diff_c(g, p->surface_model, f->st[n], f->s[n], f->evisc, f->s_fluxbot[n], f->s_fluxtop[n], f->rhoref, f->rhorefh, p->tPr, f->svisc[n], stream)) return e;
+            }
+            return MHH_OK;
         }
 #define CALL(TF) [&]{ Rhs25SmagOp<TF> op{make_grid<TF>(g), make_fields<TF>(f, p)}; return launch_interior(st, op.g, g->kstart, g->kend, op); }()
         return MHH_DISPATCH(g, CALL);

@@ -1,0 +1,313 @@
+// mhh_host.h -- C++ host side of the drop-in: the reference's operator interfaces for the hot path, implemented by
+// forwarding to the C ABI (include/mhh_hip.h).
+//
+// MicroHH selects its GPU backend at compile time: every operator's exec()/get_cfl()/... is defined once in the
+// .cxx under `#ifndef USECUDA` and once in the .cu under `#ifdef USECUDA` (src/advec_2.cxx:265 <-> src/advec_2.cu:140,
+// src/diff_smag2.cxx:882,902,937 <-> src/diff_smag2.cu:519,551,703,792,833, src/pres_2.cxx:64,97,389 <->
+// src/pres_2.cu:215). This header provides those member functions -- same names, arguments and error behaviour
+// (std::runtime_error on failure) -- over containers that mirror the slice of Grid_data / Field3d / Fields /
+// Boundary / Thermo the operators touch. INTEGRATION.md shows the same bodies written against the reference's
+// real classes (the adaptor translation units a MicroHH maintainer would add in place of the .cu files).
+//
+// Header-only, C++17, no HIP or torch types: device memory is owned by the caller (Field3d::init_device,
+// src/field3d.cu:32-47) and travels as raw pointers.
+#pragma once
+#include <array>
+#include <cmath>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../include/mhh_hip.h"
+
+namespace mhh_host
+{
+template<typename TF> constexpr int mhh_dtype();
+template<> constexpr int mhh_dtype<double>() { return MHH_F64; }
+template<> constexpr int mhh_dtype<float>()  { return MHH_F32; }
+
+inline void mhh_check(int rc) { if (rc != MHH_OK) throw std::runtime_error(std::string("mhh: ") + mhh_last_error()); }
+
+// ---- containers (subset of include/grid.h:49-135, include/field3d.h:33-81, include/fields.h:132-161) ----------
+template<typename TF>
+struct Grid_data
+{
+    int itot, jtot, ktot, imax, jmax, kmax, igc, jgc, kgc;
+    int icells, jcells, ijcells, kcells, ncells;
+    int istart, jstart, kstart, iend, jend, kend;
+    TF xsize, ysize, zsize, dx, dy;
+    std::vector<TF> z, zh, dz, dzh, dzi, dzhi, dzi4, dzhi4;                    // host metrics [kcells]
+    TF* z_g = nullptr; TF* zh_g = nullptr; TF* dz_g = nullptr; TF* dzh_g = nullptr;
+    TF* dzi_g = nullptr; TF* dzhi_g = nullptr; TF* dzi4_g = nullptr; TF* dzhi4_g = nullptr;   // device copies (Grid::prepare_device)
+    int npy = 1, mpicoordy = 0;                                                // slab decomposition (npx == 1)
+};
+
+template<typename TF>
+struct Field3d
+{
+    TF* fld_g = nullptr;
+    TF* flux_bot_g = nullptr; TF* flux_top_g = nullptr;
+    TF visc = 0;
+};
+
+template<typename TF>
+struct Fields
+{
+    using Map = std::map<std::string, std::shared_ptr<Field3d<TF>>>;
+    Map mp, mt, sp, st, sd;            // momentum / tendencies / scalars / scalar tendencies / diagnostic (evisc, p)
+    TF* rhoref_g = nullptr; TF* rhorefh_g = nullptr;
+    std::vector<TF> rhoref, rhorefh;   // host copies (Pres::set_values runs on the host)
+    TF visc = 0;
+};
+
+template<typename TF>
+struct Grid
+{
+    Grid_data<TF> gd;
+    const Grid_data<TF>& get_grid_data() const { return gd; }
+    // C-ABI descriptor with device (default) or host metric pointers
+    mhh_grid abi(bool host = false) const
+    {
+        mhh_grid g{};
+        g.itot = gd.itot; g.jtot = gd.jtot; g.ktot = gd.ktot; g.imax = gd.imax; g.jmax = gd.jmax; g.kmax = gd.kmax;
+        g.igc = gd.igc; g.jgc = gd.jgc; g.kgc = gd.kgc; g.icells = gd.icells; g.jcells = gd.jcells; g.ijcells = gd.ijcells; g.kcells = gd.kcells;
+        g.istart = gd.istart; g.jstart = gd.jstart; g.kstart = gd.kstart; g.iend = gd.iend; g.jend = gd.jend; g.kend = gd.kend;
+        g.dtype = mhh_dtype<TF>(); g.npx = 1; g.npy = gd.npy; g.mpicoordx = 0; g.mpicoordy = gd.mpicoordy;
+        g.ncells = (long long)gd.ijcells * gd.kcells;
+        g.xsize = gd.xsize; g.ysize = gd.ysize; g.zsize = gd.zsize; g.dx = gd.dx; g.dy = gd.dy;
+        if (host) { g.z = gd.z.data(); g.zh = gd.zh.data(); g.dz = gd.dz.data(); g.dzh = gd.dzh.data(); g.dzi = gd.dzi.data(); g.dzhi = gd.dzhi.data(); g.dzi4 = gd.dzi4.data(); g.dzhi4 = gd.dzhi4.data(); }
+        else      { g.z = gd.z_g; g.zh = gd.zh_g; g.dz = gd.dz_g; g.dzh = gd.dzh_g; g.dzi = gd.dzi_g; g.dzhi = gd.dzhi_g; g.dzi4 = gd.dzi4_g; g.dzhi4 = gd.dzhi4_g; }
+        return g;
+    }
+};
+
+// What Diff_smag2 reads from Boundary / Thermo (src/diff_smag2.cxx:1050-1180)
+template<typename TF>
+struct Boundary
+{
+    std::string swboundary = "default";
+    TF* z0m_g = nullptr; TF* dudz_g = nullptr; TF* dvdz_g = nullptr; TF* dbdz_g = nullptr;
+    std::string get_switch() const { return swboundary; }
+};
+template<typename TF>
+struct Thermo
+{
+    std::string swthermo = "0";
+    TF* N2_g = nullptr;            // get_thermo_field("N2") result, or null to have it evaluated from scalar `th`
+    std::string th = "th"; TF* thref_g = nullptr; TF grav = 9.81;
+    std::string get_switch() const { return swthermo; }
+};
+struct Stats {};                   // calc_tend is a no-op off sampling steps (src/stats.cxx:1893-1896)
+
+template<typename TF>
+inline mhh_fields abi_fields(const Fields<TF>& f, const Boundary<TF>* b = nullptr)
+{
+    mhh_fields a{};
+    a.u = f.mp.at("u")->fld_g; a.v = f.mp.at("v")->fld_g; a.w = f.mp.at("w")->fld_g;
+    a.ut = f.mt.at("u")->fld_g; a.vt = f.mt.at("v")->fld_g; a.wt = f.mt.at("w")->fld_g;
+    int n = 0;
+    for (auto& it : f.sp)
+    {
+        if (n >= MHH_MAX_SCALARS) throw std::runtime_error("mhh: more than MHH_MAX_SCALARS scalars");
+        a.s[n] = it.second->fld_g; a.st[n] = f.st.at(it.first)->fld_g; a.svisc[n] = it.second->visc;
+        a.s_fluxbot[n] = it.second->flux_bot_g; a.s_fluxtop[n] = it.second->flux_top_g;
+        ++n;
+    }
+    a.nscalars = n;
+    a.evisc = f.sd.count("evisc") ? f.sd.at("evisc")->fld_g : nullptr;
+    a.p = f.sd.count("p") ? f.sd.at("p")->fld_g : nullptr;
+    a.rhoref = f.rhoref_g; a.rhorefh = f.rhorefh_g; a.visc = f.visc;
+    a.u_fluxbot = f.mp.at("u")->flux_bot_g; a.u_fluxtop = f.mp.at("u")->flux_top_g;
+    a.v_fluxbot = f.mp.at("v")->flux_bot_g; a.v_fluxtop = f.mp.at("v")->flux_top_g;
+    if (b) { a.dudz = b->dudz_g; a.dvdz = b->dvdz_g; a.dbdz = b->dbdz_g; a.z0m = b->z0m_g; }
+    return a;
+}
+template<typename TF>
+inline int scalar_index(const Fields<TF>& f, const std::string& name)
+{
+    int n = 0;
+    for (auto& it : f.sp) { if (it.first == name) return n; ++n; }
+    return -1;
+}
+
+// ---- Boundary_cyclic (include/boundary_cyclic.h:35-70) ----------------------------------------------------------
+enum class Edge { East_west_edge, North_south_edge, Both_edges };
+template<typename TF>
+class Boundary_cyclic
+{
+    public:
+        explicit Boundary_cyclic(Grid<TF>& gridin) : grid(gridin) {}
+        void init() {}
+        void exec_g(TF* data, void* stream = nullptr)    { mhh_grid g = grid.abi(); mhh_check(mhh_boundary_cyclic(&g, data, MHH_EDGE_BOTH, stream)); }
+        void exec_g(TF* data, Edge e, void* stream = nullptr) { mhh_grid g = grid.abi(); mhh_check(mhh_boundary_cyclic(&g, data, static_cast<int>(e), stream)); }
+        void exec_2d_g(TF* data, void* stream = nullptr) { mhh_grid g = grid.abi(); mhh_check(mhh_boundary_cyclic_2d(&g, data, stream)); }
+    private:
+        Grid<TF>& grid;
+};
+
+// ---- Advec (include/advec.h:45-70) ----------------------------------------------------------------------------
+template<typename TF>
+class Advec
+{
+    public:
+        Advec(Grid<TF>& gridin, Fields<TF>& fieldsin, int schemein, double cflmaxin = 1.0) :
+            grid(gridin), fields(fieldsin), scheme(schemein), cflmax(cflmaxin), cflmin(1.e-5), work(nullptr) {}
+        virtual ~Advec() {}
+        // swadvec as in src/advec.cxx:55-83
+        static std::shared_ptr<Advec> factory(Grid<TF>& g, Fields<TF>& f, const std::string& swadvec, double cflmax = 1.0)
+        {
+            int s;
+            if (swadvec == "2") s = MHH_ADVEC_2; else if (swadvec == "2i5") s = MHH_ADVEC_2I5; else if (swadvec == "4") s = MHH_ADVEC_4;
+            else throw std::runtime_error("\"" + swadvec + "\" is an illegal value for swadvec");
+            return std::make_shared<Advec>(g, f, s, cflmax);
+        }
+        void set_reduce_workspace(void* device_scratch) { work = device_scratch; }   // >= mhh_reduce_work_bytes()
+        void create(Stats&) {}
+        void exec(Stats&, void* stream = nullptr)
+        {
+            mhh_grid g = grid.abi(); mhh_fields f = abi_fields(fields);
+            mhh_check(mhh_advec_exec(&g, scheme, &f, stream));
+        }
+        double get_cfl(double dt, void* stream = nullptr)
+        {
+            mhh_grid g = grid.abi(); double cfl = 0;
+            mhh_check(mhh_advec_cfl(&g, scheme, fields.mp.at("u")->fld_g, fields.mp.at("v")->fld_g, fields.mp.at("w")->fld_g, dt, work, &cfl, stream));
+            return cfl;
+        }
+        unsigned long get_time_limit(unsigned long idt, double dt, void* stream = nullptr)
+        {
+            double cfl = get_cfl(dt, stream);
+            cfl = std::max(cflmin, cfl);
+            return idt * cflmax / cfl;
+        }
+    protected:
+        Grid<TF>& grid; Fields<TF>& fields; int scheme; double cflmax; const double cflmin; void* work;
+};
+
+// ---- Diff (include/diff.h:37-71) -------------------------------------------------------------------------------
+template<typename TF>
+class Diff
+{
+    public:
+        Diff(Grid<TF>& gridin, Fields<TF>& fieldsin, Boundary<TF>& boundaryin, int schemein, double dnmaxin = 0.4, TF csin = 0.23, TF tPrin = 1./3.) :
+            tPr(tPrin), grid(gridin), fields(fieldsin), boundary(boundaryin), scheme(schemein), dnmax(dnmaxin), cs(csin), dnmul(0), mlen0_g(nullptr), work(nullptr) {}
+        virtual ~Diff() {}
+        static std::shared_ptr<Diff> factory(Grid<TF>& g, Fields<TF>& f, Boundary<TF>& b, const std::string& swdiff, double dnmax = 0.4, TF cs = 0.23, TF tPr = 1./3.)
+        {
+            int s;
+            if (swdiff == "2") s = MHH_DIFF_2; else if (swdiff == "4") s = MHH_DIFF_4; else if (swdiff == "smag2") s = MHH_DIFF_SMAG2;
+            else throw std::runtime_error("\"" + swdiff + "\" is an illegal value for swdiff");
+            return std::make_shared<Diff>(g, f, b, s, dnmax, cs, tPr);
+        }
+        void init() {}
+        void set_reduce_workspace(void* device_scratch) { work = device_scratch; }
+        // Diff_2/4::create: constant dnmul (src/diff_2.cxx:120-135); Diff_smag2 computes it per call
+        void create(Stats&)
+        {
+            auto& gd = grid.get_grid_data();
+            TF viscmax = fields.visc;
+            for (auto& it : fields.sp) viscmax = std::max(it.second->visc, viscmax);
+            dnmul = 0;
+            for (int k=gd.kstart; k<gd.kend; ++k)
+                dnmul = std::max(dnmul, std::abs(viscmax * (1./(gd.dx*gd.dx) + 1./(gd.dy*gd.dy) + 1./(gd.dz[k]*gd.dz[k]))));
+        }
+        // Diff_smag2::prepare_device (src/diff_smag2.cu:521-542): mlen0_device = caller-owned [kcells] device buffer that
+        // receives the per-level mixing length; upload(dst_device, src_host, bytes) is the caller's H2D copy
+        template<class Upload> void prepare_device(Boundary<TF>&, TF* mlen0_device, Upload upload)
+        {
+            if (scheme != MHH_DIFF_SMAG2) return;
+            auto& gd = grid.get_grid_data();
+            std::vector<TF> ml(gd.kcells);
+            mhh_grid gh = grid.abi(true);
+            mhh_check(mhh_smag2_mlen0_host(&gh, cs, ml.data()));
+            upload(mlen0_device, ml.data(), ml.size()*sizeof(TF));
+            mlen0_g = mlen0_device;
+        }
+        void clear_device() { mlen0_g = nullptr; }
+        void exec_viscosity(Thermo<TF>& thermo, void* stream = nullptr)
+        {
+            if (scheme != MHH_DIFF_SMAG2) return;
+            mhh_grid g = grid.abi(); mhh_fields f = abi_fields(fields, &boundary); mhh_diff_params p = params(&thermo);
+            mhh_check(mhh_diff_exec_viscosity(&g, scheme, &f, &p, stream));
+        }
+        void exec(Stats&, void* stream = nullptr)
+        {
+            mhh_grid g = grid.abi(); mhh_fields f = abi_fields(fields, &boundary); mhh_diff_params p = params(nullptr);
+            mhh_check(mhh_diff_exec(&g, scheme, &f, &p, stream));
+        }
+        double get_dn(double dt, void* stream = nullptr)
+        {
+            if (scheme != MHH_DIFF_SMAG2) return dnmul*dt;
+            mhh_grid g = grid.abi(); double d = 0;
+            mhh_check(mhh_smag2_dnmul(&g, fields.sd.at("evisc")->fld_g, tPr, work, &d, stream));
+            return d*dt;
+        }
+        unsigned long get_time_limit(unsigned long idt, double dt, void* stream = nullptr)
+        {
+            if (scheme != MHH_DIFF_SMAG2) return idt * dnmax / (dt * dnmul);
+            mhh_grid g = grid.abi(); double d = 0;
+            mhh_check(mhh_smag2_dnmul(&g, fields.sd.at("evisc")->fld_g, tPr, work, &d, stream));
+            d = std::max(1.e-9, d);                       // Constants::dsmall
+            return idt * dnmax / (dt * d);
+        }
+        mhh_diff_params params(Thermo<TF>* thermo) const
+        {
+            mhh_diff_params p{};
+            p.cs = cs; p.tPr = tPr; p.surface_model = (boundary.get_switch() != "default"); p.mlen0 = mlen0_g;
+            p.neutral = thermo ? (thermo->get_switch() == "0") : 0;
+            p.th_for_N2 = -1;
+            if (thermo && !p.neutral)
+            {
+                p.N2 = thermo->N2_g;
+                if (!p.N2) { p.th_for_N2 = scalar_index(fields, thermo->th); p.thref = thermo->thref_g; p.grav = thermo->grav; }
+            }
+            return p;
+        }
+        TF tPr;
+    protected:
+        Grid<TF>& grid; Fields<TF>& fields; Boundary<TF>& boundary; int scheme; double dnmax; TF cs; double dnmul; TF* mlen0_g; void* work;
+};
+
+// ---- Pres (include/pres.h:39-85) ---------------------------------------------------------------------------------
+template<typename TF>
+class Pres
+{
+    public:
+        Pres(Grid<TF>& gridin, Fields<TF>& fieldsin, int orderin) : grid(gridin), fields(fieldsin), order(orderin), plan(nullptr), work(nullptr) {}
+        virtual ~Pres() { clear_device(); }
+        static std::shared_ptr<Pres> factory(Grid<TF>& g, Fields<TF>& f, const std::string& swpres)
+        {
+            if (swpres == "2") return std::make_shared<Pres>(g, f, 2);
+            if (swpres == "4") return std::make_shared<Pres>(g, f, 4);
+            throw std::runtime_error("\"" + swpres + "\" is an illegal value for swpres");
+        }
+        void init() {}
+        void set_values() {}                  // the coefficient tables are built inside prepare_device from the host metrics
+        void create(Stats&) {}
+        void set_reduce_workspace(void* device_scratch) { work = device_scratch; }
+        void prepare_device()
+        {
+            clear_device();
+            auto& gd = grid.get_grid_data();
+            mhh_grid gh = grid.abi(true);
+            mhh_check(mhh_pres_plan_create(&gh, order, gd.dz.data(), gd.dzhi.data(), gd.dzi4.data(), gd.dzhi4.data(), fields.rhoref.data(), fields.rhorefh.data(), &plan));
+        }
+        void clear_device() { if (plan) { mhh_pres_plan_destroy(plan); plan = nullptr; } }
+        void exec(double dt, Stats&, void* stream = nullptr)
+        {
+            if (!plan) throw std::runtime_error("Pres::exec before prepare_device");
+            mhh_grid g = grid.abi(); mhh_fields f = abi_fields(fields);
+            mhh_check(mhh_pres_exec(plan, &g, &f, dt, stream));
+        }
+        TF check_divergence(void* stream = nullptr)
+        {
+            mhh_grid g = grid.abi(); mhh_fields f = abi_fields(fields); double d = 0;
+            mhh_check(mhh_pres_check_divergence(&g, order, &f, work, &d, stream));
+            return static_cast<TF>(d);
+        }
+    protected:
+        Grid<TF>& grid; Fields<TF>& fields; int order; mhh_pres_plan* plan; void* work;
+};
+
+} // namespace mhh_host

@@ -194,8 +194,8 @@ def test_operator_exec_and_fused_rhs_bitexact(be, adv, dif, sm, dtype):
     for g in (grids4(dtype) if adv == cm.ADVEC_4 else grids2(dtype)):
         if adv == cm.ADVEC_2I5 and g.jtot == 1 and dif == cm.DIFF_SMAG2 and False:
             continue
-        for nsc in (1, 2):
-            c = cm.Case(g, nscalars=nsc)
+        for nsc, rho in ((1, "random"), (2, "random"), (1, "one")):      # rho == 1 takes the kernels' division-free path
+            c = cm.Case(g, nscalars=nsc, rho=rho)
             want = _oracle_rhs(c, adv, dif, sm)
             p = capi.MhhDiffParams(); p.cs = 0.23; p.tPr = 1./3.; p.surface_model = sm
             # unfused
