@@ -245,6 +245,14 @@ int mhh_pres_fwd_x_pack       (mhh_pres_slab_plan* plan, const mhh_grid* g, void
 int mhh_pres_fwd_y_solve_bwd_y(mhh_pres_slab_plan* plan, const mhh_grid* g, void* recvbuf, void* sendbuf, void* stream);
 int mhh_pres_bwd_x_unpack     (mhh_pres_slab_plan* plan, const mhh_grid* g, void* recvbuf, const mhh_fields* f, void* stream);
 
+/* ---- Vertical ghost cells --------------------------------------------------------------
+ * Boundary::set_ghost_cells: calc_ghost_cells_{bot,top}_{2nd,4th} (src/boundary.cxx:686-836); bc 0 = Dirichlet
+ * (abot/atop), 1 = Neumann or flux (agradbot/agradtop); 2-D arrays are [ijcells]. set_ghost_cells_w (4th order
+ * only): type 0 = Normal (:874-907), 1 = Conservation (:838-871).                                              */
+int mhh_boundary_ghost_cells(const mhh_grid* g, int order, void* a, int bcbot, int bctop,
+                             const void* abot, const void* agradbot, const void* atop, const void* agradtop, void* stream);
+int mhh_boundary_ghost_cells_w(const mhh_grid* g, void* w, int type, void* stream);
+
 /* ---- Timeloop RK3/RK4 substep (src/timeloop.cxx:250-334, src/timeloop.cu:35-122) -------- */
 int mhh_rk_substep(const mhh_grid* g, int rkorder, int substep, double dt, void* a, void* at, void* stream);
 

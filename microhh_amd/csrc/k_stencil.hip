@@ -545,3 +545,74 @@ MHH_API int mhh_rk_substep(const mhh_grid* g, int rkorder, int substep, double d
     MHH_LAUNCH_CHECK();
     return MHH_OK;
 }
+
+// =======================================================================================================
+// Vertical ghost cells: Boundary::set_ghost_cells / set_ghost_cells_w
+// (src/boundary.cxx:686-907, 919-1007; GPU src/boundary.cu:119-300). bc: 0 Dirichlet, 1 Neumann / flux.
+// =======================================================================================================
+template<class TF>
+struct GhostOp
+{
+    GridDev<TF> g; int order, bcbot, bctop; TF* __restrict__ a;
+    const TF* __restrict__ abot; const TF* __restrict__ agradbot; const TF* __restrict__ atop; const TF* __restrict__ agradtop;
+    const TF* __restrict__ dzh;
+    __device__ void operator()(int i, int j, int, int) const
+    {
+        const int jj = g.icells, kk = g.ijcells, ks = g.kstart, ke = g.kend;
+        const int ij = i + j*jj, b = ij + ks*kk, t = ij + (ke-1)*kk;
+        if (order == 2)
+        {
+            if (bcbot == 0) a[b-kk] = TF(2.)*abot[ij] - a[b]; else a[b-kk] = -agradbot[ij]*dzh[ks] + a[b];
+            if (bctop == 0) a[t+kk] = TF(2.)*atop[ij] - a[t]; else a[t+kk] = agradtop[ij]*dzh[ke] + a[t];
+        }
+        else
+        {
+            const TF cg0 = TF(1./24.), cg1 = TF(-27./24.);
+            if (bcbot == 0) { a[b-kk] = TF(8./3.)*abot[ij] - TF(2.)*a[b] + TF(1./3.)*a[b+kk]; a[b-2*kk] = TF(8.)*abot[ij] - TF(9.)*a[b] + TF(2.)*a[b+kk]; }
+            else
+            {
+                const TF gr = ( - cg0*(g.z[ks+1]-g.z[ks-2]) - cg1*(g.z[ks]-g.z[ks-1]) );
+                a[b-kk] = TF(-1.)*gr*agradbot[ij] + a[b]; a[b-2*kk] = TF(-3.)*gr*agradbot[ij] + a[b+kk];
+            }
+            if (bctop == 0) { a[t+kk] = TF(8./3.)*atop[ij] - TF(2.)*a[t] + TF(1./3.)*a[t-kk]; a[t+2*kk] = TF(8.)*atop[ij] - TF(9.)*a[t] + TF(2.)*a[t-kk]; }
+            else
+            {
+                const TF gr = ( - cg0*(g.z[ke+1]-g.z[ke-2]) - cg1*(g.z[ke]-g.z[ke-1]) );
+                a[t+kk] = TF(1.)*gr*agradtop[ij] + a[t]; a[t+2*kk] = TF(3.)*gr*agradtop[ij] + a[t-kk];
+            }
+        }
+    }
+};
+MHH_API int mhh_boundary_ghost_cells(const mhh_grid* g, int order, void* a, int bcbot, int bctop,
+                                     const void* abot, const void* agradbot, const void* atop, const void* agradtop, void* stream)
+{
+    if (int e = check_grid(g)) return e;
+    MHH_REQUIRE(order == 2 || order == 4, "order");
+    MHH_REQUIRE(a && (bcbot == 0 ? abot : agradbot) && (bctop == 0 ? atop : agradtop), "null field");
+    MHH_REQUIRE((bcbot == 0 || bcbot == 1) && (bctop == 0 || bctop == 1), "bc type: 0 Dirichlet, 1 Neumann");
+    MHH_REQUIRE(g->kgc >= (order == 2 ? 1 : 2) && g->dzh, "ghost levels");
+#define CALL(TF) [&]{ GhostOp<TF> op{make_grid<TF>(g), order, bcbot, bctop, mp<TF>(a), cp<TF>(abot), cp<TF>(agradbot), cp<TF>(atop), cp<TF>(agradtop), cp<TF>(g->dzh)}; \
+                      return launch_cells(as_stream(stream), op, 0, g->icells, 0, g->jcells, 0, 1, g->icells, g->ijcells); }()
+    return MHH_DISPATCH(g, CALL);
+#undef CALL
+}
+template<class TF>
+struct GhostWOp
+{
+    GridDev<TF> g; int type; TF* __restrict__ w;
+    __device__ void operator()(int i, int j, int, int) const
+    {
+        const int kk = g.ijcells, b = i + j*g.icells + g.kstart*kk, t = i + j*g.icells + g.kend*kk;
+        if (type == 1) { w[b-kk] = -w[b+kk]; w[b-2*kk] = -w[b+2*kk]; w[t+kk] = -w[t-kk]; w[t+2*kk] = -w[t-2*kk]; }
+        else { w[b-kk] = TF(-6.)*w[b+kk] + TF(4.)*w[b+2*kk] - w[b+3*kk]; w[t+kk] = TF(-6.)*w[t-kk] + TF(4.)*w[t-2*kk] - w[t-3*kk]; }
+    }
+};
+MHH_API int mhh_boundary_ghost_cells_w(const mhh_grid* g, void* w, int type, void* stream)
+{
+    if (int e = check_grid(g)) return e;
+    MHH_REQUIRE(w && (type == 0 || type == 1) && g->kgc >= 2 && g->kmax >= 3, "4th-order w ghost cells: type 0 Normal / 1 Conservation, kgc >= 2");
+#define CALL(TF) [&]{ GhostWOp<TF> op{make_grid<TF>(g), type, mp<TF>(w)}; \
+                      return launch_cells(as_stream(stream), op, 0, g->icells, 0, g->jcells, 0, 1, g->icells, g->ijcells); }()
+    return MHH_DISPATCH(g, CALL);
+#undef CALL
+}

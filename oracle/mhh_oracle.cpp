@@ -1337,6 +1337,56 @@ void rk_substep(const mhh_grid& g, int order, int substep, TF dt, TF* a, TF* at)
             }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Boundary::set_ghost_cells / set_ghost_cells_w (src/boundary.cxx:686-907, 919-1007). bc: 0 Dirichlet, 1 Neumann/flux
+// ---------------------------------------------------------------------------------------------
+template<class TF>
+void ghost_cells(const mhh_grid& g, int order, TF* a, int bcbot, int bctop, const TF* abot, const TF* agradbot, const TF* atop, const TF* agradtop)
+{
+    const int jj = g.icells, kk = g.ijcells;
+    const TF* dzh = P<TF>(g.dzh); const TF* z = P<TF>(g.z);
+    const int ks = g.kstart, ke = g.kend;
+    for (int j=0; j<g.jcells; ++j)
+        for (int i=0; i<g.icells; ++i)
+        {
+            const int ij = i + j*jj;
+            const int b = ij + ks*kk, t = ij + (ke-1)*kk;
+            if (order == 2)
+            {
+                if (bcbot == 0) a[b-kk] = TF(2.)*abot[ij] - a[b]; else a[b-kk] = -agradbot[ij]*dzh[ks] + a[b];
+                if (bctop == 0) a[t+kk] = TF(2.)*atop[ij] - a[t]; else a[t+kk] = agradtop[ij]*dzh[ke] + a[t];
+            }
+            else
+            {
+                if (bcbot == 0) { a[b-kk] = TF(8./3.)*abot[ij] - TF(2.)*a[b] + TF(1./3.)*a[b+kk]; a[b-2*kk] = TF(8.)*abot[ij] - TF(9.)*a[b] + TF(2.)*a[b+kk]; }
+                else
+                {
+                    const TF gr = ( - W4<TF>::cg0*(z[ks+1]-z[ks-2]) - W4<TF>::cg1*(z[ks]-z[ks-1]) );      // grad4, finite_difference.h:128
+                    a[b-kk] = TF(-1.)*gr*agradbot[ij] + a[b]; a[b-2*kk] = TF(-3.)*gr*agradbot[ij] + a[b+kk];
+                }
+                if (bctop == 0) { a[t+kk] = TF(8./3.)*atop[ij] - TF(2.)*a[t] + TF(1./3.)*a[t-kk]; a[t+2*kk] = TF(8.)*atop[ij] - TF(9.)*a[t] + TF(2.)*a[t-kk]; }
+                else
+                {
+                    const TF gr = ( - W4<TF>::cg0*(z[ke+1]-z[ke-2]) - W4<TF>::cg1*(z[ke]-z[ke-1]) );
+                    a[t+kk] = TF(1.)*gr*agradtop[ij] + a[t]; a[t+2*kk] = TF(3.)*gr*agradtop[ij] + a[t-kk];
+                }
+            }
+        }
+}
+// 4th-order w ghost cells: type 0 = Normal (extrapolation), 1 = Conservation (mirror)
+template<class TF>
+void ghost_cells_w(const mhh_grid& g, TF* w, int type)
+{
+    const int jj = g.icells, kk = g.ijcells;
+    for (int j=0; j<g.jcells; ++j)
+        for (int i=0; i<g.icells; ++i)
+        {
+            const int b = i + j*jj + g.kstart*kk, t = i + j*jj + g.kend*kk;
+            if (type == 1) { w[b-kk] = -w[b+kk]; w[b-2*kk] = -w[b+2*kk]; w[t+kk] = -w[t-kk]; w[t+2*kk] = -w[t-2*kk]; }
+            else { w[b-kk] = TF(-6.)*w[b+kk] + TF(4.)*w[b+2*kk] - w[b+3*kk]; w[t+kk] = TF(-6.)*w[t-kk] + TF(4.)*w[t-2*kk] - w[t-3*kk]; }
+        }
+}
+
 } // namespace
 
 // =================================================================================================
@@ -1490,3 +1540,8 @@ ORC_API void orc_pres2_coeffs(const mhh_grid* g, const void* rh, double* bmati, 
 
 ORC_API void orc_rk_substep(const mhh_grid* g, int order, int substep, double dt, void* a, void* at)
 { DISPATCH(g, rk_substep<double>(*g, order, substep, dt, D(a), D(at)), rk_substep<float>(*g, order, substep, (float)dt, F(a), F(at))); }
+
+ORC_API void orc_ghost_cells(const mhh_grid* g, int order, void* a, int bcbot, int bctop, const void* abot, const void* agradbot, const void* atop, const void* agradtop)
+{ DISPATCH(g, ghost_cells<double>(*g, order, D(a), bcbot, bctop, D(abot), D(agradbot), D(atop), D(agradtop)), ghost_cells<float>(*g, order, F(a), bcbot, bctop, F(abot), F(agradbot), F(atop), F(agradtop))); }
+ORC_API void orc_ghost_cells_w(const mhh_grid* g, void* w, int type)
+{ DISPATCH(g, ghost_cells_w<double>(*g, D(w), type), ghost_cells_w<float>(*g, F(w), type)); }
