@@ -13,9 +13,20 @@
 //   * the next plane is prefetched into registers while the current one is being computed (loads in flight
 //     across the whole compute phase), then written to the LDS ring between two barriers.
 // Accumulation order per tendency is the reference's: t += advec_horizontal; t += advec_vertical; t += diffusion.
+#include <cstdint>
+#include <cstdlib>
 #include "k_common.h"
+#include <gfx950_prims.h>   // angle form: the CPU emulation build (tests/emul) overrides it by include path
 
 using namespace mhh;
+
+// Diagnostic build only (-DMHH_MARCH_STAMPS): per-segment cycle sums of the marching loop, never compiled into the product.
+#ifdef MHH_MARCH_STAMPS
+__device__ unsigned long long g_march_stamps[8];
+#define STAMP(n) do { const unsigned long long t_ = clock64(); stamp_acc[n] += t_ - stamp_t; stamp_t = t_; } while (0)
+#else
+#define STAMP(n)
+#endif
 
 namespace
 {
@@ -82,17 +93,30 @@ __device__ __forceinline__ bool decode_march(const MarchTiling& t, unsigned L, i
     return by < t.nby;
 }
 
-template<class TF, int NJ, bool HAS_S>
-__global__ void __launch_bounds__(64*NJ, 2) rhs25_march_kernel(const GridDev<TF> g, const MarchFields<TF> f, const MarchTiling mt)
+#ifndef MHH_MARCH_OCC
+#define MHH_MARCH_OCC 2
+#endif
+// DMA = true : planes travel global -> LDS with global_load_lds_dwordx4 (no staging registers, no ds_write, one
+//              barrier per level; rings one slot deeper so that the copy of the next plane can run under the whole
+//              compute phase). Needs 16-byte aligned rows: icells % (16/sizeof(TF)) == 0 and 16-byte aligned fields.
+// DMA = false: planes are staged through registers (prefetch, two barriers per level): any alignment.
+template<class TF, int NJ, bool HAS_S, bool DMA>
+__global__ void __launch_bounds__(64*NJ, MHH_MARCH_OCC) rhs25_march_kernel(const GridDev<TF> g, const MarchFields<TF> f, const MarchTiling mt)
 {
-    constexpr int TI = 70, TJ = NJ + 6, TE = 66, TJE = NJ + 2, NT = 64*NJ;
+    constexpr int VEC = 16 / (int)sizeof(TF);                       // elements per 16-byte DMA piece
+    constexpr int TI = DMA ? ((70 + VEC-1)/VEC)*VEC : 70;           // u,v,w,s tile: x from i0-3
+    constexpr int EX = DMA ? VEC : 1;                               // evisc tile: x from i0-EX (aligned for DMA)
+    constexpr int TE = DMA ? ((64 + EX + 1 + VEC-1)/VEC)*VEC : 66;
+    constexpr int TJ = NJ + 6, TJE = NJ + 2, NT = 64*NJ;
     constexpr int NTILE = TI*TJ, NETILE = TE*TJE;
-    constexpr int NLD = (NTILE + NT - 1) / NT, NLDE = (NETILE + NT - 1) / NT;
-    __shared__ TF U[3][NTILE];
-    __shared__ TF V[3][NTILE];
-    __shared__ TF W[3][NTILE];
-    __shared__ TF S[HAS_S ? 2 : 1][HAS_S ? NTILE : 1];
-    __shared__ TF E[3][NETILE];
+    constexpr int RU = DMA ? 3 : 2, RW = DMA ? 3 : 2, RE = DMA ? 4 : 3, RS = DMA ? 2 : 1;
+    // LDS rings: only the planes a level reads with horizontal offsets are kept -- u, v: k-1 and k (their k+1 values
+    // are needed at the thread's own column only: register window); w: k and k+1; evisc: k-1..k+1; scalar: k.
+    __shared__ __attribute__((aligned(16))) TF U[RU][NTILE];
+    __shared__ __attribute__((aligned(16))) TF V[RU][NTILE];
+    __shared__ __attribute__((aligned(16))) TF W[RW][NTILE];
+    __shared__ __attribute__((aligned(16))) TF S[HAS_S ? RS : 1][HAS_S ? NTILE : VEC];
+    __shared__ __attribute__((aligned(16))) TF E[RE][NETILE];
 
     int bx, by, kcn;
     if (!decode_march(mt, blockIdx.x, bx, by, kcn)) return;        // whole block leaves together: no barrier hazard
@@ -106,29 +130,35 @@ __global__ void __launch_bounds__(64*NJ, 2) rhs25_march_kernel(const GridDev<TF>
     const int ci = (i < g.iend) ? i : g.iend-1, cj = (j < g.jend) ? j : g.jend-1;   // clamped column for the window loads
     const int col = ci + cj*jj;
     const int ij = col;
-    const int l = (ty+3)*TI + (tx+3), le = (ty+1)*TE + (tx+1);
+    const int l = (ty+3)*TI + (tx+3), le = (ty+1)*TE + (tx+EX);
+    auto slot = [](int p, int r) { return (p + 12) % r; };            // 12 is a multiple of every ring depth
 
-    // ---- tile movers: element e = tid + n*NT of the (TJ x TI) tile; global offsets within a plane computed once -----
+    // ---- tile movers. A tile is walked in pieces of PV elements: e = tid + n*NT; piece -> (row, first column) ------
+    constexpr int PV = DMA ? VEC : 1;
+    constexpr int PPR = TI / PV, PPRE = TE / PV;                      // pieces per tile row
+    constexpr int NP = PPR*TJ, NPE = PPRE*TJE;
+    constexpr int NLD = (NP + NT - 1) / NT, NLDE = (NPE + NT - 1) / NT;
     int off[NLD], offe[NLDE];
     bool okt[NLD], oke[NLDE];
 #pragma unroll
     for (int n=0; n<NLD; ++n)
     {
         const int e = tid + n*NT;
-        const int tj = e / TI, ti = e - tj*TI;
+        const int tj = e / PPR, ti = (e - tj*PPR)*PV;
         const int gi = i0 - 3 + ti, gj = j0 - 3 + tj;
-        okt[n] = (e < NTILE) && (gi < g.icells) && (gj < g.jcells);
+        okt[n] = (e < NP) && (gi + PV <= g.icells) && (gj < g.jcells);
         off[n] = okt[n] ? gi + gj*jj : 0;
     }
 #pragma unroll
     for (int n=0; n<NLDE; ++n)
     {
         const int e = tid + n*NT;
-        const int tj = e / TE, ti = e - tj*TE;
-        const int gi = i0 - 1 + ti, gj = j0 - 1 + tj;
-        oke[n] = (e < NETILE) && (gi < g.icells) && (gj < g.jcells);
+        const int tj = e / PPRE, ti = (e - tj*PPRE)*PV;
+        const int gi = i0 - EX + ti, gj = j0 - 1 + tj;
+        oke[n] = (e < NPE) && (gi + PV <= g.icells) && (gj < g.jcells);
         offe[n] = oke[n] ? gi + gj*jj : 0;
     }
+    // register-staged movers
     auto ld_tile = [&](const TF* __restrict__ fld, int kp, TF (&r)[NLD])
     {
         const bool kok = (kp >= 0) && (kp < g.kcells);
@@ -139,7 +169,7 @@ __global__ void __launch_bounds__(64*NJ, 2) rhs25_march_kernel(const GridDev<TF>
     auto st_tile = [&](TF* __restrict__ lds, const TF (&r)[NLD])
     {
 #pragma unroll
-        for (int n=0; n<NLD; ++n) { const int e = tid + n*NT; if (n+1 < NLD || e < NTILE) lds[e] = r[n]; }
+        for (int n=0; n<NLD; ++n) { const int e = tid + n*NT; if (n+1 < NLD || e < NP) lds[e] = r[n]; }
     };
     auto ld_etile = [&](int kp, TF (&r)[NLDE])
     {
@@ -151,26 +181,53 @@ __global__ void __launch_bounds__(64*NJ, 2) rhs25_march_kernel(const GridDev<TF>
     auto st_etile = [&](TF* __restrict__ lds, const TF (&r)[NLDE])
     {
 #pragma unroll
-        for (int n=0; n<NLDE; ++n) { const int e = tid + n*NT; if (n+1 < NLDE || e < NETILE) lds[e] = r[n]; }
+        for (int n=0; n<NLDE; ++n) { const int e = tid + n*NT; if (n+1 < NLDE || e < NPE) lds[e] = r[n]; }
+    };
+    // LDS-DMA movers: 16 bytes per lane straight into the ring slot; lanes outside the tile / the array sit out
+    const int wave_e0 = tid & ~63;                                    // first piece index of this wave within a sweep
+    auto dma_tile = [&](const TF* __restrict__ fld, int kp, TF* __restrict__ lds)
+    {
+        if (kp < 0 || kp >= g.kcells) return;                         // wave-uniform
+        const TF* __restrict__ pl = fld + (size_t)kp*kk;
+#pragma unroll
+        for (int n=0; n<NLD; ++n)
+            if (okt[n]) lds_dma16(pl + off[n], lds + (size_t)(wave_e0 + n*NT)*PV);
+    };
+    auto dma_etile = [&](int kp, TF* __restrict__ lds)
+    {
+        if (kp < 0 || kp >= g.kcells) return;
+        const TF* __restrict__ pl = f.ev + (size_t)kp*kk;
+#pragma unroll
+        for (int n=0; n<NLDE; ++n)
+            if (oke[n]) lds_dma16(pl + offe[n], lds + (size_t)(wave_e0 + n*NT)*PV);
     };
     auto colval = [&](const TF* __restrict__ fld, int kp) -> TF
     {
         return (kp >= 0 && kp < g.kcells) ? fld[col + kp*kk] : TF(0);
     };
-    auto slot = [](int p) { return (p + 3) % 3; };
 
-    // ---- prologue: planes ks-1, ks, ks+1 into the ring, scalar plane ks, windows centred on ks ------------------
+    // ---- prologue: the planes level ks reads, scalar plane ks, windows centred on ks ------------------------------
     const int ks = kb - 1;                 // warm-up level: only top-face quantities are formed there
+    if constexpr (DMA)
+    {
+        for (int p = ks-1; p <= ks+1; ++p)
+        {
+            if (p <= ks) { dma_tile(f.u, p, U[slot(p, RU)]); dma_tile(f.v, p, V[slot(p, RU)]); }
+            if (p >= ks) dma_tile(f.w, p, W[slot(p, RW)]);
+            dma_etile(p, E[slot(p, RE)]);
+        }
+        if (HAS_S) dma_tile(f.s, ks, S[slot(ks, RS)]);
+    }
+    else
     {
         TF r[NLD]; TF re[NLDE];
         for (int p = ks-1; p <= ks+1; ++p)
         {
-            ld_tile(f.u, p, r); st_tile(U[slot(p)], r);
-            ld_tile(f.v, p, r); st_tile(V[slot(p)], r);
-            ld_tile(f.w, p, r); st_tile(W[slot(p)], r);
-            ld_etile(p, re);    st_etile(E[slot(p)], re);
+            if (p <= ks) { ld_tile(f.u, p, r); st_tile(U[slot(p, RU)], r); ld_tile(f.v, p, r); st_tile(V[slot(p, RU)], r); }
+            if (p >= ks) { ld_tile(f.w, p, r); st_tile(W[slot(p, RW)], r); }
+            ld_etile(p, re);    st_etile(E[slot(p, RE)], re);
         }
-        if (HAS_S) { ld_tile(f.s, ks, r); st_tile(S[ks & 1], r); }
+        if (HAS_S) { ld_tile(f.s, ks, r); st_tile(S[0], r); }
     }
     TF uw[7], vw[7], ww[7], sw[7];
 #pragma unroll
@@ -179,6 +236,7 @@ __global__ void __launch_bounds__(64*NJ, 2) rhs25_march_kernel(const GridDev<TF>
         uw[n] = colval(f.u, ks-3+n); vw[n] = colval(f.v, ks-3+n); ww[n] = colval(f.w, ks-3+n);
         sw[n] = HAS_S ? colval(f.s, ks-3+n) : TF(0);
     }
+    if constexpr (DMA) wait_vmem();
     __syncthreads();
 
     // carried bottom-face products: advective centred (T) and upwind (G) parts, diffusive flux (D)
@@ -188,38 +246,55 @@ __global__ void __launch_bounds__(64*NJ, 2) rhs25_march_kernel(const GridDev<TF>
     const TF dxd = g.dxi_d, dyd = g.dyi_d;          // diffusion spelling TF(1./dx)
     const TF visc = f.visc;
 
+#ifdef MHH_MARCH_STAMPS
+    unsigned long long stamp_acc[8] = {0,0,0,0,0,0,0,0}; unsigned long long stamp_t = clock64();
+#endif
     for (int k = ks; k < ke; ++k)
     {
-        // ---- prefetch for the next level: plane k+2 of u, v, w, evisc; plane k+1 of s; window value k+4 ---------
-        TF pu[NLD], pv[NLD], pw[NLD], ps[NLD], pe[NLDE];
+        STAMP(0);
+        // ---- start moving the next level's planes: k+1 of u, v, s; k+2 of w, evisc; window value k+4 ---------------
+        TF pu[NLD], pv[NLD], pw[NLD], ps[NLD], pe[NLDE];        // staging registers (unused, and removed, in the DMA variant)
         const bool more = (k + 1 < ke);
         if (more)
         {
-            ld_tile(f.u, k+2, pu); ld_tile(f.v, k+2, pv); ld_tile(f.w, k+2, pw); ld_etile(k+2, pe);
-            if (HAS_S) ld_tile(f.s, k+1, ps);
+            if constexpr (DMA)
+            {
+                dma_tile(f.u, k+1, U[slot(k+1, RU)]); dma_tile(f.v, k+1, V[slot(k+1, RU)]); dma_tile(f.w, k+2, W[slot(k+2, RW)]);
+                dma_etile(k+2, E[slot(k+2, RE)]);
+                if (HAS_S) dma_tile(f.s, k+1, S[slot(k+1, RS)]);
+            }
+            else
+            {
+                ld_tile(f.u, k+1, pu); ld_tile(f.v, k+1, pv); ld_tile(f.w, k+2, pw); ld_etile(k+2, pe);
+                if (HAS_S) ld_tile(f.s, k+1, ps);
+            }
         }
         const TF nu = more ? colval(f.u, k+4) : TF(0), nv = more ? colval(f.v, k+4) : TF(0), nw = more ? colval(f.w, k+4) : TF(0);
         const TF ns = (more && HAS_S) ? colval(f.s, k+4) : TF(0);
 
-        const TF* __restrict__ uk = U[slot(k)] + l;  const TF* __restrict__ ukm = U[slot(k-1)] + l;
-        const TF* __restrict__ vk = V[slot(k)] + l;  const TF* __restrict__ vkm = V[slot(k-1)] + l;
-        const TF* __restrict__ wk = W[slot(k)] + l;  const TF* __restrict__ wkp = W[slot(k+1)] + l;
-        const TF* __restrict__ sk = S[HAS_S ? (k & 1) : 0] + (HAS_S ? l : 0);
-        const TF* __restrict__ ek = E[slot(k)] + le; const TF* __restrict__ ekm = E[slot(k-1)] + le; const TF* __restrict__ ekp = E[slot(k+1)] + le;
-
+        const TF* __restrict__ uk = U[slot(k, RU)] + l;  const TF* __restrict__ ukm = U[slot(k-1, RU)] + l;
+        const TF* __restrict__ vk = V[slot(k, RU)] + l;  const TF* __restrict__ vkm = V[slot(k-1, RU)] + l;
+        const TF* __restrict__ wk = W[slot(k, RW)] + l;  const TF* __restrict__ wkp = W[slot(k+1, RW)] + l;
+        const TF* __restrict__ sk = S[HAS_S ? slot(k, RS) : 0] + (HAS_S ? l : 0);
+        const TF* __restrict__ ek = E[slot(k, RE)] + le; const TF* __restrict__ ekm = E[slot(k-1, RE)] + le; const TF* __restrict__ ekp = E[slot(k+1, RE)] + le;
         // per-level coefficients (wave-uniform)
         const TF rhkp = f.rhorefh[k+1], rhk = f.rhorefh[k], rk = f.rhoref[k];
         const TF dzi = g.dzi[k], dzhi = g.dzhi[k], dzhip = g.dzhi[k+1];
         const bool rk1 = (rk == TF(1.)), rhk1 = (rhk == TF(1.));
+#ifdef MHH_HACK_ORDER6      // timing experiment only (wrong near the walls): no order dispatch
+        constexpr int otc = 6, obc = 6, otw = 6, obw = 6; const bool wlev = true;
+#else
         const int otc = order_face_c(k+1, g.kstart, g.kend);
         const int obc = order_face_c(k, g.kstart, g.kend);
         const bool wlev = (k >= g.kstart);                       // the w equation's "faces" are cell centres kstart..kend-1
         const int otw = wlev ? order_face_w(k, g.kstart, g.kend) : 0;
         const int obw = (k-1 >= g.kstart) ? order_face_w(k-1, g.kstart, g.kend) : 0;
+#endif
         // surface model: the lowest / highest level takes the prescribed flux instead of the resolved one
         const bool fb = f.sm && (k == g.kstart), ft = f.sm && (k == g.kend-1);
         const bool need_dtop = !(ft) && (k < g.kend-1 || !f.sm) && (k+1 <= g.kend);   // top diffusive flux of level k is used by k or k+1
 
+        STAMP(1);
         // ---- top-face quantities of level k --------------------------------------------------------------------
         TF Tu = 0, Gu = 0, Tv = 0, Gv = 0, Tw = 0, Gw = 0, Ts = 0, Gs = 0;
         if (otc != 0)
@@ -260,6 +335,7 @@ __global__ void __launch_bounds__(64*NJ, 2) rhs25_march_kernel(const GridDev<TF>
             Dw = rk * etw*(ww[4]-ww[3])*dzi;
         }
 
+        STAMP(2);
         // ---- update the tendencies of level k ----------------------------------------------------------------
         if (k >= kb && active)
         {
@@ -304,13 +380,11 @@ __global__ void __launch_bounds__(64*NJ, 2) rhs25_march_kernel(const GridDev<TF>
             }
             if (k > g.kstart)
             {   // w
-                const TF rkm = f.rhoref[k-1];
                 const TF ue = i2(ukm[1], uk[1]), uwf = i2(ukm[0], uk[0]);
                 const TF vn = i2(vkm[TI], vk[TI]), vs = i2(vkm[0], vk[0]);
                 TF t = f.wt[c];
                 t += advec25_hor(wk, 0, TI, ue, uwf, vn, vs, dxi, dyi);
                 t += vert_combine(otw, obw, Tw, cTw, Gw, cGw, rhk, rhk1, dzhi);
-                (void)rkm;
                 const TF ee = TF(0.25)*(ekm[0  ] + ek[0  ] + ekm[1 ] + ek[1 ]) + visc;
                 const TF ew = TF(0.25)*(ekm[-1 ] + ek[-1 ] + ekm[0 ] + ek[0 ]) + visc;
                 const TF en = TF(0.25)*(ekm[0  ] + ek[0  ] + ekm[TE] + ek[TE]) + visc;
@@ -341,17 +415,34 @@ __global__ void __launch_bounds__(64*NJ, 2) rhs25_march_kernel(const GridDev<TF>
                 f.st[c] = t;
             }
         }
-        // ---- carry the top faces down, rotate the ring, shift the windows --------------------------------------
+        STAMP(3);
+        // ---- carry the top faces down, rotate the rings, shift the windows --------------------------------------------
         cTu = Tu; cGu = Gu; cDu = Du; cTv = Tv; cGv = Gv; cDv = Dv; cTw = Tw; cGw = Gw; cDw = Dw; cTs = Ts; cGs = Gs; cDs = Ds;
         if (more)
         {
-            __syncthreads();                                   // everyone is done reading plane k-1 (and scalar plane k)
-            st_tile(U[slot(k+2)], pu); st_tile(V[slot(k+2)], pv); st_tile(W[slot(k+2)], pw); st_etile(E[slot(k+2)], pe);
-            if (HAS_S) st_tile(S[(k+1) & 1], ps);
-            __syncthreads();
+            if constexpr (DMA)
+            {
+                wait_vmem();                                       // this wave's copies have landed (and its stores have left)
+                STAMP(4);
+                __syncthreads();                                   // ... everyone's have, and everyone is done with the oldest planes
+                STAMP(6);
+            }
+            else
+            {
+                __syncthreads();                                   // everyone is done reading the planes that are about to be replaced
+                STAMP(4);
+                st_tile(U[slot(k+1, RU)], pu); st_tile(V[slot(k+1, RU)], pv); st_tile(W[slot(k+2, RW)], pw); st_etile(E[slot(k+2, RE)], pe);
+                if (HAS_S) st_tile(S[0], ps);
+                STAMP(5);
+                __syncthreads();
+                STAMP(6);
+            }
             shift(uw, nu); shift(vw, nv); shift(ww, nw); shift(sw, ns);
         }
     }
+#ifdef MHH_MARCH_STAMPS
+    if ((threadIdx.x & 63) == 0) for (int n=0; n<8; ++n) atomicAdd(&g_march_stamps[n], stamp_acc[n]);
+#endif
 }
 
 template<class TF>
@@ -380,8 +471,21 @@ int march_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* 
     t.sr = (MHH_STRIP_ROWS + NJ-1)/NJ; if (t.sr < 1) t.sr = 1;
     t.ns = (t.nby + t.sr-1)/t.sr;
     const unsigned nblocks = 8u * (unsigned)((t.ns + 7)/8) * (unsigned)t.sr * t.nbx * t.nkc;
-    if (has_s) hipLaunchKernelGGL((rhs25_march_kernel<TF, NJ, true>),  dim3(nblocks), dim3(64, NJ), 0, st, gd, mf, t);
-    else       hipLaunchKernelGGL((rhs25_march_kernel<TF, NJ, false>), dim3(nblocks), dim3(64, NJ), 0, st, gd, mf, t);
+    // LDS-DMA needs 16-byte aligned plane rows; otherwise the register-staged variant runs (same arithmetic)
+    constexpr int VEC = 16 / (int)sizeof(TF);
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+    static const bool no_dma = [] { const char* e = getenv("MHH_MARCH_DMA"); return e && !strcmp(e, "0"); }();
+    const bool dma = !no_dma && (g->icells % VEC == 0) && al16(f->u) && al16(f->v) && al16(f->w) && al16(f->evisc) && (!has_s || al16(f->s[0]));
+    if (dma)
+    {
+        if (has_s) hipLaunchKernelGGL((rhs25_march_kernel<TF, NJ, true, true>),  dim3(nblocks), dim3(64, NJ), 0, st, gd, mf, t);
+        else       hipLaunchKernelGGL((rhs25_march_kernel<TF, NJ, false, true>), dim3(nblocks), dim3(64, NJ), 0, st, gd, mf, t);
+    }
+    else
+    {
+        if (has_s) hipLaunchKernelGGL((rhs25_march_kernel<TF, NJ, true, false>),  dim3(nblocks), dim3(64, NJ), 0, st, gd, mf, t);
+        else       hipLaunchKernelGGL((rhs25_march_kernel<TF, NJ, false, false>), dim3(nblocks), dim3(64, NJ), 0, st, gd, mf, t);
+    }
     MHH_LAUNCH_CHECK();
     return MHH_OK;
 }
@@ -393,3 +497,13 @@ int mhh_rhs25_march(const mhh_grid* g, const mhh_fields* f, const mhh_diff_param
     if (g->dtype == MHH_F64) return march_launch<double>(g, f, p, as_stream(stream));
     return march_launch<float>(g, f, p, as_stream(stream));
 }
+
+#ifdef MHH_MARCH_STAMPS
+extern "C" __attribute__((visibility("default"))) int mhh_debug_march_stamps(unsigned long long* out)
+{
+    unsigned long long z[8] = {0,0,0,0,0,0,0,0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_march_stamps), sizeof(z)) != hipSuccess) return 1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_march_stamps), z, sizeof(z)) != hipSuccess) return 1;
+    return 0;
+}
+#endif

@@ -18,6 +18,7 @@ d=json.load(open(sys.argv[1])); print("%-28s ms/step %7.3f  rhs ms %7.3f  value 
 PY
 }
 run march512 X=1 -- --workload drycblles512
+run march512_nodma MHH_MARCH_DMA=0 -- --workload drycblles512
 run cell512 MHH_RHS25_IMPL=cell -- --workload drycblles512
 run march256 X=1 -- --workload drycblles256
 run cell256 MHH_RHS25_IMPL=cell -- --workload drycblles256

@@ -1,0 +1,13 @@
+// tests/emul/gfx950_prims.h -- TEST-ONLY override of microhh_amd/csrc/gfx950_prims.h for the CPU emulation build.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstring>
+namespace mhh
+{
+inline void lds_dma16(const void* gsrc, void* lds_wave_base)
+{
+    const unsigned lane = (threadIdx.x + threadIdx.y*blockDim.x + threadIdx.z*blockDim.x*blockDim.y) & 63u;
+    std::memcpy(static_cast<char*>(lds_wave_base) + lane*16, gsrc, 16);
+}
+inline void wait_vmem() {}
+}
