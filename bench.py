@@ -27,6 +27,7 @@ WORKLOADS = {
     "drycblles512": ("drycblles", 512, 512, 512, "drycblles 512^3 fp64, advec_2i5 + diff_smag2 + pres_2 (BASELINE.json configs[3] grid on N GPUs)"),
     "drycblles256": ("drycblles", 256, 256, 256, "drycblles 256^3 fp64, advec_2i5 + diff_smag2 + pres_2 (BASELINE.json configs[1])"),
     "moser600": ("moser600", 512, 256, 256, "moser600 512x256x256 fp64, advec_4 + diff_4 + pres_4 (BASELINE.json configs[2])"),
+    "slab8of512": ("drycblles", 512, 64, 512, "one rank's share (512x64x512) of drycblles 512^3 on 8 GPUs, run alone: per-rank compute estimate"),
     "taylorgreen64": ("taylorgreen", 64, 64, 64, "taylorgreen 64^3 fp64, advec_2 + diff_2 + pres_2 (BASELINE.json configs[0])"),
 }
 
@@ -87,6 +88,7 @@ def main():
     ap.add_argument("--workload", default="drycblles512", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="time Advec::exec + Diff::exec as separate launches")
+    ap.add_argument("--force-slab", action="store_true", help="N=1 only: run the slab code path (halo pack/unpack, split pressure solve) with local copies as exchanges")
     args = ap.parse_args()
 
     import torch
@@ -101,7 +103,8 @@ def main():
 
     case, itot, jtot, ktot, desc = WORKLOADS[args.workload]
     from microhh_amd.model import HotPath
-    hp = HotPath(case, itot, jtot, ktot, device="cuda:%d" % local, npy=world, rank=rank)   # slab in y: npx=1, npy=world
+    hp = HotPath(case, itot, jtot, ktot, device="cuda:%d" % local, npy=world, rank=rank,   # slab in y: npx=1, npy=world
+                 force_slab=(args.force_slab and world == 1))
 
     rhs = hp.rhs_unfused if args.unfused else hp.rhs
 

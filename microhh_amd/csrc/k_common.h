@@ -76,26 +76,31 @@ constexpr int BX = MHH_BX, BY = MHH_BY;    // BX must stay a multiple of 64 (wav
 // (measured: 6x the algorithmic HBM bytes on the fused 2i5+smag2 pass at 512^3). So each XCD gets whole
 // "strips" of SR block-rows (all i), and walks a strip plane by plane in k before taking its next strip:
 // the live working set of an XCD is (rows of a strip + halo) x (planes of the stencil + planes in flight).
-struct Tiling { int nbx, nby, nk, sr, ns; };
+struct Tiling { int nbx, nby, nk, sr, ns, nseg, kseg; };
 #ifndef MHH_STRIP_ROWS
 #define MHH_STRIP_ROWS 16          // grid rows per strip (tuned on MI355X)
 #endif
 
+// A "unit" is one strip (sr block-rows, all i) over one k-segment; units are dealt to the XCDs round-robin and a unit
+// is walked plane by plane. nseg > 1 only when there are fewer than 8 strips (thin slabs of a multi-GPU run), so
+// that all 8 XCDs still get work.
 __device__ __forceinline__ bool decode_tile(const Tiling& t, unsigned L, int& bx, int& by, int& kz)
 {
     const int xcd = L & 7u;
     const unsigned tt = L >> 3;
-    const unsigned per_strip = (unsigned)t.sr * t.nbx * t.nk;
-    const unsigned round = tt / per_strip;
-    unsigned r = tt - round * per_strip;
-    const int strip = (int)round * 8 + xcd;
-    if (strip >= t.ns) return false;
+    const unsigned per_unit = (unsigned)t.sr * t.nbx * t.kseg;
+    const unsigned round = tt / per_unit;
+    unsigned r = tt - round * per_unit;
+    const int unit = (int)round * 8 + xcd;
+    if (unit >= t.ns * t.nseg) return false;
+    const int strip = unit % t.ns, seg = unit / t.ns;
     const unsigned per_plane = (unsigned)t.sr * t.nbx;
-    kz = (int)(r / per_plane); r -= (unsigned)kz * per_plane;
+    const int kl = (int)(r / per_plane); r -= (unsigned)kl * per_plane;
     const int byl = (int)(r / t.nbx);
     bx = (int)(r - (unsigned)byl * t.nbx);
     by = strip * t.sr + byl;
-    return by < t.nby;
+    kz = seg * t.kseg + kl;
+    return (by < t.nby) && (kz < t.nk);
 }
 
 template<class Op>
@@ -114,11 +119,16 @@ inline Tiling make_tiling(int ni, int nj, int nk)
 {
     Tiling t;
     t.nbx = (ni + BX-1)/BX; t.nby = (nj + BY-1)/BY; t.nk = nk;
-    t.sr = (MHH_STRIP_ROWS + BY-1)/BY; if (t.sr < 1) t.sr = 1;
+    t.sr = (MHH_STRIP_ROWS + BY-1)/BY;
+    if (t.sr > t.nby/8) t.sr = t.nby/8;          // at least 8 strips when the slab is tall enough
+    if (t.sr < 1) t.sr = 1;
     t.ns = (t.nby + t.sr-1)/t.sr;
+    t.nseg = (t.ns >= 8) ? 1 : (8 + t.ns-1)/t.ns;
+    if (t.nseg > nk) t.nseg = nk;
+    t.kseg = (nk + t.nseg-1)/t.nseg;
     return t;
 }
-inline unsigned tiling_blocks(const Tiling& t) { return 8u * (unsigned)((t.ns + 7)/8) * (unsigned)t.sr * t.nbx * t.nk; }
+inline unsigned tiling_blocks(const Tiling& t) { const int units = t.ns*t.nseg; return 8u * (unsigned)((units + 7)/8) * (unsigned)t.sr * t.nbx * t.kseg; }
 
 template<class Op>
 inline int launch_cells(hipStream_t st, const Op& op, int i0, int i1, int j0, int j1, int k0, int k1, int jj, int kk)

@@ -77,16 +77,17 @@ struct MarchTiling { int nbx, nby, nkc, sr, ns, kc; };
 
 __device__ __forceinline__ bool decode_march(const MarchTiling& t, unsigned L, int& bx, int& by, int& kc)
 {
-    // same XCD-aware strip order as decode_tile (k_common.h), with k-chunks in place of k-planes
+    // XCD-aware order as decode_tile (k_common.h): a unit = one strip of tiles over one k-chunk; units are dealt to the
+    // XCDs round-robin, so the tiles that share halos run next to each other on one L2.
     const int xcd = L & 7u;
     const unsigned tt = L >> 3;
-    const unsigned per_strip = (unsigned)t.sr * t.nbx * t.nkc;
-    const unsigned round = tt / per_strip;
-    unsigned r = tt - round * per_strip;
-    const int strip = (int)round * 8 + xcd;
-    if (strip >= t.ns) return false;
-    const unsigned per_chunk = (unsigned)t.sr * t.nbx;
-    kc = (int)(r / per_chunk); r -= (unsigned)kc * per_chunk;
+    const unsigned per_unit = (unsigned)t.sr * t.nbx;
+    const unsigned round = tt / per_unit;
+    unsigned r = tt - round * per_unit;
+    const int unit = (int)round * 8 + xcd;
+    if (unit >= t.ns * t.nkc) return false;
+    const int strip = unit % t.ns;
+    kc = unit / t.ns;
     const int byl = (int)(r / t.nbx);
     bx = (int)(r - (unsigned)byl * t.nbx);
     by = strip * t.sr + byl;
@@ -468,9 +469,12 @@ int march_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* 
 #define MHH_MARCH_KC 128
 #endif
     t.kc = MHH_MARCH_KC; t.nkc = (g->kmax + t.kc - 1)/t.kc;
-    t.sr = (MHH_STRIP_ROWS + NJ-1)/NJ; if (t.sr < 1) t.sr = 1;
+    t.sr = (MHH_STRIP_ROWS + NJ-1)/NJ;
+    if (t.sr * 8 > t.nby * t.nkc) t.sr = (t.nby * t.nkc) / 8;     // enough (strip, chunk) units to occupy all 8 XCDs
+    if (t.sr < 1) t.sr = 1;
     t.ns = (t.nby + t.sr-1)/t.sr;
-    const unsigned nblocks = 8u * (unsigned)((t.ns + 7)/8) * (unsigned)t.sr * t.nbx * t.nkc;
+    const int units = t.ns * t.nkc;
+    const unsigned nblocks = 8u * (unsigned)((units + 7)/8) * (unsigned)t.sr * t.nbx;
     // LDS-DMA needs 16-byte aligned plane rows; otherwise the register-staged variant runs (same arithmetic)
     constexpr int VEC = 16 / (int)sizeof(TF);
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };

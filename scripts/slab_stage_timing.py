@@ -1,0 +1,53 @@
+"""Per-rank compute time of the slab-decomposed pipeline at its REAL per-rank shape (e.g. rank 0 of 8 on 512^3), on
+one GPU: the exchanges are skipped (buffers keep whatever they hold), only the kernels either side are timed."""
+import ctypes as C, os, sys, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from microhh_amd import capi
+from microhh_amd.model import HotPath
+
+npy = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+lib = capi.lib()
+hp = HotPath("drycblles", n, n, n, npy=npy, rank=0, group=None, global_init=None) if False else None
+# build the rank-0 object without a process group: construct with npy ranks but never call the exchanges
+class NoComm(HotPath):
+    def halo(self, tensors):
+        arr = self._ptrs(tensors)
+        self._ok(self.lib.mhh_boundary_cyclic_n(self.G, arr, len(tensors), 0, self.stream))
+        nf = len(tensors)
+        if nf not in self._halo:
+            m = int(self.lib.mhh_halo_buffer_elems(self.G, nf))
+            self._halo[nf] = [torch.zeros(m, device=self.device, dtype=self.td) for _ in range(4)]
+        s_south, s_north, r_south, r_north = self._halo[nf]
+        self._ok(self.lib.mhh_halo_pack_ns(self.G, arr, nf, s_south.data_ptr(), s_north.data_ptr(), self.stream))
+        self._ok(self.lib.mhh_halo_unpack_ns(self.G, arr, nf, s_north.data_ptr(), s_south.data_ptr(), self.stream))
+    def _transpose(self):
+        pass
+hp = NoComm("drycblles", n, n, n, npy=npy, rank=0)
+def timeit(fn, reps=10):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b)/reps
+lib, st = hp.lib, hp.stream
+packed = lib.mhh_pres_slab_packed(hp.plan)
+f = C.byref(hp.fields)
+res = {
+ "cyclic_prognostic(4 fields)": timeit(hp.cyclic_prognostic),
+ "exec_viscosity+halo": timeit(hp.exec_viscosity),
+ "rhs": timeit(hp.rhs),
+ "halo(vt)": timeit(lambda: hp.halo([hp.vt])),
+ "pres_input": timeit(lambda: lib.mhh_pres_input_packed(hp.G, 2, f, 1.0, packed, st)),
+ "fwd_x_pack": timeit(lambda: lib.mhh_pres_fwd_x_pack(hp.plan, hp.G, packed, hp.xsend.data_ptr(), st)),
+ "fwd_y_solve_bwd_y": timeit(lambda: lib.mhh_pres_fwd_y_solve_bwd_y(hp.plan, hp.G, hp.xrecv.data_ptr(), hp.xsend.data_ptr(), st)),
+ "bwd_x_unpack": timeit(lambda: lib.mhh_pres_bwd_x_unpack(hp.plan, hp.G, hp.xrecv.data_ptr(), f, st)),
+ "halo(p)": timeit(lambda: hp.halo([hp.p])),
+ "pres_output": timeit(lambda: lib.mhh_pres_output_order(hp.G, 2, f, st)),
+ "full step (no comm)": timeit(hp.step),
+}
+for k, v in res.items(): print("%-32s %8.3f ms" % (k, v))
+print("all-to-all volume per rank per direction: %.1f MB" % (hp.xsend.numel()*8/1e6))
