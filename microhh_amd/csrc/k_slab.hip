@@ -213,66 +213,111 @@ __global__ void __launch_bounds__(256) xbuf_x_kernel(C2<TF>* __restrict__ specx,
     if (FWD) xbuf[xb] = (kx < nxh) ? specx[sx] : C2<TF>{0, 0};
     else if (kx < nxh) specx[sx] = xbuf[xb];
 }
-// xbuf [r][k][jl][kxl] <-> specy [k][kxl][j = r*jmax + jl]
+// xbuf [r][k][jl][kxl] <-> specy [k][kxl][j = r*jmax + jl]: per (k, r) a 2-D transpose of a (jmax x nxb) matrix of complex
+// numbers, done through an LDS tile of 64 (j) x 32 (kxl) so that both the global reads and the global writes are
+// contiguous runs (512 B rows on the xbuf side, 1 KB rows on the specy side). The tile rows are padded by one element:
+// a transposed ds_read_b128 then touches 16 different 4-bank groups per lane group (no conflicts).
 template<class TF, bool FWD>
 __global__ void __launch_bounds__(256) xbuf_y_kernel(C2<TF>* __restrict__ specy, C2<TF>* __restrict__ xbuf, int nxb, int jmax, int jtot, int ktot)
 {
-    const int j = blockIdx.x*256 + threadIdx.x;
-    const int kxl = blockIdx.y, k = blockIdx.z;
-    if (j >= jtot) return;
-    const int r = j / jmax, jl = j - r*jmax;
-    const size_t xb = (((size_t)r*ktot + k)*jmax + jl)*nxb + kxl;
-    const size_t sy = ((size_t)k*nxb + kxl)*jtot + j;
-    if (FWD) specy[sy] = xbuf[xb]; else xbuf[xb] = specy[sy];
+    constexpr int TJ = 64, TX = 32;
+    __shared__ C2<TF> tile[TJ][TX+1];
+    const int ntx = (nxb + TX-1)/TX, njl = (jmax + TJ-1)/TJ;
+    int b = blockIdx.x;
+    const int txi = b % ntx; b /= ntx;
+    const int jli = b % njl; const int r = b / njl;
+    const int k = blockIdx.y;
+    const int kx0 = txi*TX, jl0 = jli*TJ;
+    const int t = threadIdx.x;
+    const size_t xb0 = ((size_t)r*ktot + k)*jmax*nxb;            // start of the (r,k) matrix [jl][kxl]
+    const size_t sy0 = (size_t)k*nxb*jtot + (size_t)r*jmax;      // specy element (k, kxl=0, j=r*jmax)
+    if (FWD)
+    {
+        for (int p = 0; p < TJ*TX/256; ++p)                      // 8 passes: 8 rows x 32 columns each
+        {
+            const int row = p*8 + t/32, cx = t % 32;
+            const int jl = jl0 + row, kxl = kx0 + cx;
+            if (jl < jmax && kxl < nxb) tile[row][cx] = xbuf[xb0 + (size_t)jl*nxb + kxl];
+        }
+        __syncthreads();
+        for (int p = 0; p < TJ*TX/256; ++p)                      // 8 passes: 4 columns x 64 rows each
+        {
+            const int cx = p*4 + t/64, row = t % 64;
+            const int jl = jl0 + row, kxl = kx0 + cx;
+            if (jl < jmax && kxl < nxb) specy[sy0 + (size_t)kxl*jtot + jl] = tile[row][cx];
+        }
+    }
+    else
+    {
+        for (int p = 0; p < TJ*TX/256; ++p)
+        {
+            const int cx = p*4 + t/64, row = t % 64;
+            const int jl = jl0 + row, kxl = kx0 + cx;
+            if (jl < jmax && kxl < nxb) tile[row][cx] = specy[sy0 + (size_t)kxl*jtot + jl];
+        }
+        __syncthreads();
+        for (int p = 0; p < TJ*TX/256; ++p)
+        {
+            const int row = p*8 + t/32, cx = t % 32;
+            const int jl = jl0 + row, kxl = kx0 + cx;
+            if (jl < jmax && kxl < nxb) xbuf[xb0 + (size_t)jl*nxb + kxl] = tile[row][cx];
+        }
+    }
 }
 
-// Thomas algorithm on specy, one thread per (ky, kxl) column, ky fastest (src/pres_2.cxx:289-330, :202-263)
+// Thomas algorithm on specy (src/pres_2.cxx:289-330 matrix, :202-263 tdma). One thread per (ky, re|im) COMPONENT of a
+// column: the matrix is real, so the two components are independent solves with the same pivots; splitting them
+// doubles the parallelism of a sweep that has only nxb*jtot columns per rank (33 x 512 at 512^3 on 8 GPUs), and the
+// lanes of a wave still read consecutive 8-byte words. The pivot recurrence does not depend on the right-hand
+// side, so the loads of the next levels are free to run ahead of it (unrolled by 4).
 template<class TF>
-__global__ void __launch_bounds__(64) tdma_slab_kernel(C2<TF>* __restrict__ p, TF* __restrict__ work3d,
-                                                       const TF* __restrict__ bmati, const TF* __restrict__ bmatj,
-                                                       const TF* __restrict__ a, const TF* __restrict__ c, const TF* __restrict__ dz, const TF* __restrict__ rho,
-                                                       int nxh, int nxb, int kx0, int jtot, int kmax)
+__global__ void __launch_bounds__(128) tdma_slab_kernel(TF* __restrict__ p, TF* __restrict__ work3d,
+                                                        const TF* __restrict__ bmati, const TF* __restrict__ bmatj,
+                                                        const TF* __restrict__ a, const TF* __restrict__ c, const TF* __restrict__ dz, const TF* __restrict__ rho,
+                                                        int nxh, int nxb, int kx0, int jtot, int kmax)
 {
-    const int ky = blockIdx.x*64 + threadIdx.x, kxl = blockIdx.y;
+    const int t = blockIdx.x*128 + threadIdx.x;           // 0 .. 2*jtot-1
+    const int ky = t >> 1, comp = t & 1, kxl = blockIdx.y;
     const int kx = kx0 + kxl;                              // swapped indices: this rank owns a block of x modes, all y modes
     if (ky >= jtot || kx >= nxh) return;
     const size_t kk = (size_t)nxb*jtot, col = (size_t)kxl*jtot + ky;
+    TF* __restrict__ q = p + 2*col + comp;                 // component stream, stride 2*kk per level
     const TF bm = bmati[kx] + bmatj[ky];
     const bool mean = (kx == 0 && ky == 0);
-    TF w2; C2<TF> pp;
+    TF w2, pp;
     {
         const TF dz2 = dz[0]*dz[0];
         TF b = dz2 * rho[0]*bm - (a[0]+c[0]);
         b += a[0];
         if (kmax == 1) { if (mean) b -= c[0]; else b += c[0]; }
-        C2<TF> q = p[col];
-        q.x = dz2 * q.x; q.y = dz2 * q.y;
+        TF v = dz2 * q[0];
         w2 = b;
-        q.x /= w2; q.y /= w2;
-        p[col] = q; pp = q;
+        v /= w2;
+        q[0] = v; pp = v;
     }
+#pragma unroll 4
     for (int k=1; k<kmax; ++k)
     {
-        const size_t e = col + (size_t)k*kk;
+        const size_t e = (size_t)k*kk;
         const TF dz2 = dz[k]*dz[k];
         TF b = dz2 * rho[k]*bm - (a[k]+c[k]);
         if (k == kmax-1) { if (mean) b -= c[k]; else b += c[k]; }
-        C2<TF> q = p[e];
-        q.x = dz2 * q.x; q.y = dz2 * q.y;
+        TF v = dz2 * q[2*e];
         const TF w3 = c[k-1] / w2;
-        work3d[e] = w3;
+        work3d[col + e] = w3;          // both components store the same value: each later reads what it wrote itself
         w2 = b - a[k]*w3;
-        q.x -= a[k]*pp.x; q.y -= a[k]*pp.y;
-        q.x /= w2; q.y /= w2;
-        p[e] = q; pp = q;
+        v -= a[k]*pp;
+        v /= w2;
+        q[2*e] = v; pp = v;
     }
+#pragma unroll 4
     for (int k=kmax-2; k>=0; --k)
     {
-        const size_t e = col + (size_t)k*kk;
-        const TF w3 = work3d[e+kk];
-        C2<TF> q = p[e];
-        q.x -= w3*pp.x; q.y -= w3*pp.y;
-        p[e] = q; pp = q;
+        const size_t e = (size_t)k*kk;
+        const TF w3 = work3d[col + e + kk];
+        TF v = q[2*e];
+        v -= w3*pp;
+        q[2*e] = v; pp = v;
     }
 }
 
@@ -321,15 +366,15 @@ MHH_API int mhh_pres_fwd_y_solve_bwd_y(mhh_pres_slab_plan* P, const mhh_grid* g,
     MHH_REQUIRE(recvbuf && sendbuf, "buffers");
     hipStream_t st = as_stream(stream);
     MHH_FFT_TRY(rocfft_execution_info_set_stream(P->info, st));
-    dim3 gy((P->jtot + 255)/256, P->nxb, P->ktot);
-    dim3 gs((P->jtot + 63)/64, P->nxb);
+    dim3 gy((unsigned)(((P->nxb + 31)/32) * ((P->jmax + 63)/64) * P->npy), P->ktot);
+    dim3 gs((2*P->jtot + 127)/128, P->nxb);
     void* io[1] = {P->specy};
     if (g->dtype == MHH_F64)
     {
         hipLaunchKernelGGL((xbuf_y_kernel<double, true>), gy, dim3(256), 0, st, (C2<double>*)P->specy, (C2<double>*)recvbuf, P->nxb, P->jmax, P->jtot, P->ktot);
         MHH_LAUNCH_CHECK();
         MHH_FFT_TRY(rocfft_execute(P->fy, io, nullptr, P->info));
-        hipLaunchKernelGGL(tdma_slab_kernel<double>, gs, dim3(64), 0, st, (C2<double>*)P->specy, (double*)P->work, cp<double>(P->bmati), cp<double>(P->bmatj),
+        hipLaunchKernelGGL(tdma_slab_kernel<double>, gs, dim3(128), 0, st, (double*)P->specy, (double*)P->work, cp<double>(P->bmati), cp<double>(P->bmatj),
                            cp<double>(P->a), cp<double>(P->c), cp<double>(P->dz), cp<double>(P->rhoref), P->nxh, P->nxb, P->rank*P->nxb, P->jtot, P->ktot);
         MHH_LAUNCH_CHECK();
         MHH_FFT_TRY(rocfft_execute(P->by, io, nullptr, P->info));
@@ -340,7 +385,7 @@ MHH_API int mhh_pres_fwd_y_solve_bwd_y(mhh_pres_slab_plan* P, const mhh_grid* g,
         hipLaunchKernelGGL((xbuf_y_kernel<float, true>), gy, dim3(256), 0, st, (C2<float>*)P->specy, (C2<float>*)recvbuf, P->nxb, P->jmax, P->jtot, P->ktot);
         MHH_LAUNCH_CHECK();
         MHH_FFT_TRY(rocfft_execute(P->fy, io, nullptr, P->info));
-        hipLaunchKernelGGL(tdma_slab_kernel<float>, gs, dim3(64), 0, st, (C2<float>*)P->specy, (float*)P->work, cp<float>(P->bmati), cp<float>(P->bmatj),
+        hipLaunchKernelGGL(tdma_slab_kernel<float>, gs, dim3(128), 0, st, (float*)P->specy, (float*)P->work, cp<float>(P->bmati), cp<float>(P->bmatj),
                            cp<float>(P->a), cp<float>(P->c), cp<float>(P->dz), cp<float>(P->rhoref), P->nxh, P->nxb, P->rank*P->nxb, P->jtot, P->ktot);
         MHH_LAUNCH_CHECK();
         MHH_FFT_TRY(rocfft_execute(P->by, io, nullptr, P->info));

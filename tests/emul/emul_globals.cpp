@@ -2,6 +2,7 @@
 thread_local uint3e blockIdx, threadIdx;
 thread_local dim3 blockDim, gridDim;
 EmulState g_emul;
+bool g_emul_saw_barrier = false;
 extern "C" void emul_fiber_entry()
 {
     g_emul.body();

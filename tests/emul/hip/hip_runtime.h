@@ -45,10 +45,10 @@ struct EmulFiber { ucontext_t ctx; std::vector<char> stack; bool done = false; u
 struct EmulState { ucontext_t sched; EmulFiber* cur = nullptr; std::function<void()> body; };
 extern EmulState g_emul;
 extern "C" void emul_fiber_entry();
-struct EmulNeedsFibers {};
-// A kernel is first run with plain calls (fast). The first __syncthreads() met in that mode aborts the block,
-// and the launch site switches to fiber mode for good (work done before the first barrier is simply redone).
-inline void __syncthreads() { if (!g_emul.cur) throw EmulNeedsFibers(); swapcontext(&g_emul.cur->ctx, &g_emul.sched); }
+// The first block of every launch site runs on fibers and records whether any thread reached a barrier; if none
+// did, later blocks of that launch site run as plain calls (fast path).
+extern bool g_emul_saw_barrier;
+inline void __syncthreads() { g_emul_saw_barrier = true; swapcontext(&g_emul.cur->ctx, &g_emul.sched); }
 
 template<class F>
 inline void emul_launch(dim3 grid, dim3 block, F&& body)
@@ -58,24 +58,21 @@ inline void emul_launch(dim3 grid, dim3 block, F&& body)
     static std::vector<EmulFiber> fibers;
     if (fibers.size() < nthreads) fibers.resize(nthreads);
     g_emul.body = [&]{ body(); };
-    static bool need_fibers = false;          // one flag per launch site (this template is instantiated per kernel lambda)
+    static int need_fibers = -1;              // one flag per launch site (this template is instantiated per kernel lambda): -1 unknown
     for (unsigned bz=0; bz<grid.z; ++bz) for (unsigned by=0; by<grid.y; ++by) for (unsigned bx=0; bx<grid.x; ++bx)
     {
         blockIdx = {bx, by, bz};
-        if (!need_fibers)
+        if (need_fibers == 0)
         {
             g_emul.cur = nullptr;
-            try
+            for (int tz=(int)block.z-1; tz>=0; --tz) for (int ty=(int)block.y-1; ty>=0; --ty) for (int tx=(int)block.x-1; tx>=0; --tx)
             {
-                for (int tz=(int)block.z-1; tz>=0; --tz) for (int ty=(int)block.y-1; ty>=0; --ty) for (int tx=(int)block.x-1; tx>=0; --tx)
-                {
-                    threadIdx = {(unsigned)tx, (unsigned)ty, (unsigned)tz};
-                    body();
-                }
-                continue;
+                threadIdx = {(unsigned)tx, (unsigned)ty, (unsigned)tz};
+                body();
             }
-            catch (const EmulNeedsFibers&) { need_fibers = true; }
+            continue;
         }
+        if (need_fibers < 0) g_emul_saw_barrier = false;
         size_t n = 0;
         for (int tz=(int)block.z-1; tz>=0; --tz) for (int ty=(int)block.y-1; ty>=0; --ty) for (int tx=(int)block.x-1; tx>=0; --tx)
         {
@@ -99,6 +96,7 @@ inline void emul_launch(dim3 grid, dim3 block, F&& body)
                 if (!f.done) alive = true;
             }
         }
+        if (need_fibers < 0) need_fibers = g_emul_saw_barrier ? 1 : 0;
     }
 }
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) emul_launch(grid, block, [&]{ kernel(__VA_ARGS__); })
