@@ -181,6 +181,7 @@ MHH_API void mhh_pres_plan_destroy(mhh_pres_plan* P)
     delete P;
 }
 
+static int hdma_factor(mhh_pres_plan* P);
 MHH_API int mhh_pres_plan_create(const mhh_grid* g, int order, const void* host_dz, const void* host_dzhi, const void* host_dzi4, const void* host_dzhi4,
                                  const void* host_rhoref, const void* host_rhorefh, mhh_pres_plan** out)
 {
@@ -196,7 +197,7 @@ MHH_API int mhh_pres_plan_create(const mhh_grid* g, int order, const void* host_
     int e = (g->dtype == MHH_F64) ? plan_tables<double>(P, g, host_dz, host_dzhi, host_dzi4, host_dzhi4, host_rhoref, host_rhorefh)
                                   : plan_tables<float>(P, g, host_dz, host_dzhi, host_dzi4, host_dzhi4, host_rhoref, host_rhorefh);
     const size_t nreal = (size_t)g->itot*g->jtot*g->ktot, ncol = (size_t)P->nxh*g->jtot;
-    const size_t nwork = (order == 2) ? ncol*g->ktot : ncol*(g->ktot+4)*9;   // pres_4: 7 bands + complex rhs
+    const size_t nwork = (order == 2) ? ncol*g->ktot : ncol*(g->ktot+4)*7;   // pres_4: the 7 factored bands
     if (!e) { hipError_t h = hipMalloc(&P->packed, nreal*P->esz); if (h != hipSuccess) { set_error("hipMalloc packed: %s", hipGetErrorString(h)); e = MHH_ENOMEM; } }
     if (!e) { hipError_t h = hipMalloc(&P->spec, ncol*g->ktot*2*P->esz); if (h != hipSuccess) { set_error("hipMalloc spec: %s", hipGetErrorString(h)); e = MHH_ENOMEM; } }
     if (!e) { hipError_t h = hipMalloc(&P->work, nwork*P->esz); if (h != hipSuccess) { set_error("hipMalloc work: %s", hipGetErrorString(h)); e = MHH_ENOMEM; } }
@@ -207,6 +208,7 @@ MHH_API int mhh_pres_plan_create(const mhh_grid* g, int order, const void* host_
         e = make_fft(P, true, &P->fwd, &P->fwd_info, &P->fwd_wb);
         if (!e) e = make_fft(P, false, &P->bwd, &P->bwd_info, &P->bwd_wb);
     }
+    if (!e && order == 4) e = hdma_factor(P);
     if (e) { mhh_pres_plan_destroy(P); return e; }
     *out = P;
     return MHH_OK;
@@ -322,10 +324,12 @@ __global__ void __launch_bounds__(64) tdma_kernel(C2<TF>* __restrict__ p, TF* __
 
 // =======================================================================================================
 // spectral solve, pres_4: 7-band LU without pivoting on kmax+4 unknowns per column (src/pres_4.cxx:358-470, hdma :574-730)
-// Scratch layout: band n (0..6) at W[(n*(kmax+4) + k)*ncol + col], rhs (complex) behind the bands.
+// The band matrix depends on the grid and (kx,ky) only, so its LU factors are computed once at plan creation
+// (hdma_factor_kernel, the reference's elimination order) and kept: band n (0..6) at W[(n*(kmax+4) + k)*ncol + col].
+// Every solve is then the two substitution sweeps (hdma_solve_kernel), in place on the spectral array.
 // =======================================================================================================
 template<class TF>
-__global__ void __launch_bounds__(64) hdma_kernel(C2<TF>* __restrict__ p, TF* __restrict__ W,
+__global__ void __launch_bounds__(64) hdma_factor_kernel(TF* __restrict__ W,
                                                   const TF* __restrict__ bmati, const TF* __restrict__ bmatj,
                                                   const TF* __restrict__ M1, const TF* __restrict__ M2, const TF* __restrict__ M3, const TF* __restrict__ M4,
                                                   const TF* __restrict__ M5, const TF* __restrict__ M6, const TF* __restrict__ M7,
@@ -335,31 +339,27 @@ __global__ void __launch_bounds__(64) hdma_kernel(C2<TF>* __restrict__ p, TF* __
     if (kx >= nxh) return;
     const size_t ncol = (size_t)nxh*jtot, col = kx + (size_t)ky*nxh;
     const int n = kmax+4;
-    const TF bm = bmati[kx] + bmatj[ky];
     const bool mean = (kx == 0 && ky == 0);
     TF* __restrict__ m1 = W + 0*(size_t)n*ncol + col; TF* __restrict__ m2 = W + 1*(size_t)n*ncol + col;
     TF* __restrict__ m3 = W + 2*(size_t)n*ncol + col; TF* __restrict__ m4 = W + 3*(size_t)n*ncol + col;
     TF* __restrict__ m5 = W + 4*(size_t)n*ncol + col; TF* __restrict__ m6 = W + 5*(size_t)n*ncol + col;
     TF* __restrict__ m7 = W + 6*(size_t)n*ncol + col;
-    C2<TF>* __restrict__ q = reinterpret_cast<C2<TF>*>(W + 7*(size_t)n*ncol) + col;
 #define A(arr, k) arr[(size_t)(k)*ncol]
     // fill (rows 0,1: bottom bc; 2..kmax+1: interior; kmax+2, kmax+3: top bc)
-    A(m1,0)=0; A(m2,0)=0; A(m3,0)=0; A(m4,0)=1; A(m5,0)=0;  A(m6,0)=0; A(m7,0)=-1; A(q,0) = C2<TF>{0,0};
-    A(m1,1)=0; A(m2,1)=0; A(m3,1)=0; A(m4,1)=1; A(m5,1)=-1; A(m6,1)=0; A(m7,1)=0;  A(q,1) = C2<TF>{0,0};
+    A(m1,0)=0; A(m2,0)=0; A(m3,0)=0; A(m4,0)=1; A(m5,0)=0;  A(m6,0)=0; A(m7,0)=-1;
+    A(m1,1)=0; A(m2,1)=0; A(m3,1)=0; A(m4,1)=1; A(m5,1)=-1; A(m6,1)=0; A(m7,1)=0;
     for (int k=0; k<kmax; ++k)
     {
         A(m1,k+2)=M1[k]; A(m2,k+2)=M2[k]; A(m3,k+2)=M3[k]; A(m4,k+2)=M4[k] + bmati[kx] + bmatj[ky];
         A(m5,k+2)=M5[k]; A(m6,k+2)=M6[k]; A(m7,k+2)=M7[k];
-        A(q,k+2) = p[col + (size_t)k*ncol];
     }
-    (void)bm;
     const int t = kmax+2;
     if (mean) { A(m1,t)=TF(0.);    A(m2,t)=TF(-1/3.); A(m3,t)=TF(2.);  A(m4,t)=TF(1.);
                 A(m1,t+1)=TF(-2.); A(m2,t+1)=TF(9.);  A(m3,t+1)=TF(0.); A(m4,t+1)=TF(1.); }
     else      { A(m1,t)=TF(0.);    A(m2,t)=TF(0.);    A(m3,t)=TF(-1.); A(m4,t)=TF(1.);
                 A(m1,t+1)=TF(-1.); A(m2,t+1)=TF(0.);  A(m3,t+1)=TF(0.); A(m4,t+1)=TF(1.); }
-    A(m5,t)=0; A(m6,t)=0; A(m7,t)=0; A(q,t) = C2<TF>{0,0};
-    A(m5,t+1)=0; A(m6,t+1)=0; A(m7,t+1)=0; A(q,t+1) = C2<TF>{0,0};
+    A(m5,t)=0; A(m6,t)=0; A(m7,t)=0;
+    A(m5,t+1)=0; A(m6,t+1)=0; A(m7,t+1)=0;
     // LU
     int k = 0;
     A(m1,k)=1; A(m2,k)=1; A(m3,k)=TF(1.)/A(m4,k); A(m4,k)=1; A(m5,k)=A(m5,k)*A(m3,k); A(m6,k)=A(m6,k)*A(m3,k); A(m7,k)=A(m7,k)*A(m3,k);
@@ -384,34 +384,72 @@ __global__ void __launch_bounds__(64) hdma_kernel(C2<TF>* __restrict__ p, TF* __
         if (k == kmax+2) { A(m6,k)=TF(1.); A(m7,k)=TF(1.); }
         if (k == kmax+3) { A(m5,k)=TF(1.); A(m6,k)=TF(1.); A(m7,k)=TF(1.); }
     }
-    // L y = q
-    { C2<TF> q0 = A(q,0), q1 = A(q,1), q2 = A(q,2);
-      q0.x = q0.x*A(m3,0); q0.y = q0.y*A(m3,0);
-      q1.x = q1.x - q0.x*A(m3,1); q1.y = q1.y - q0.y*A(m3,1);
-      q2.x = q2.x - q1.x*A(m3,2) - q0.x*A(m2,2); q2.y = q2.y - q1.y*A(m3,2) - q0.y*A(m2,2);
-      A(q,0) = q0; A(q,1) = q1; A(q,2) = q2; }
-    for (k=3; k<kmax+4; ++k)
+#undef A
+}
+
+static int hdma_factor(mhh_pres_plan* P)
+{
+    dim3 grid((P->nxh + 63)/64, P->jtot);
+    if (P->dtype == MHH_F64)
+        hipLaunchKernelGGL(hdma_factor_kernel<double>, grid, dim3(64), 0, 0, (double*)P->work, cp<double>(P->bmati), cp<double>(P->bmatj),
+                           cp<double>(P->m[0]), cp<double>(P->m[1]), cp<double>(P->m[2]), cp<double>(P->m[3]), cp<double>(P->m[4]), cp<double>(P->m[5]), cp<double>(P->m[6]),
+                           P->nxh, P->jtot, P->ktot);
+    else
+        hipLaunchKernelGGL(hdma_factor_kernel<float>, grid, dim3(64), 0, 0, (float*)P->work, cp<float>(P->bmati), cp<float>(P->bmatj),
+                           cp<float>(P->m[0]), cp<float>(P->m[1]), cp<float>(P->m[2]), cp<float>(P->m[3]), cp<float>(P->m[4]), cp<float>(P->m[5]), cp<float>(P->m[6]),
+                           P->nxh, P->jtot, P->ktot);
+    hipError_t h = hipGetLastError(); if (h == hipSuccess) h = hipStreamSynchronize(0);
+    if (h != hipSuccess) { set_error("hdma_factor: %s", hipGetErrorString(h)); return MHH_EHIP; }
+    return MHH_OK;
+}
+
+// One thread per (column, re|im): the substitutions act on the two components independently. Unknown row r of the
+// reference's kmax+4 system is spectral level r-2; the two boundary rows on either side have a zero right-hand side
+// and live in registers only, so the sweeps run in place on p without a scratch copy of the rhs.
+template<class TF>
+__global__ void __launch_bounds__(128) hdma_solve_kernel(TF* __restrict__ p, const TF* __restrict__ W, size_t ncol, int kmax)
+{
+    const size_t t = (size_t)blockIdx.x*128 + threadIdx.x;
+    if (t >= 2*ncol) return;
+    const size_t col = t >> 1;
+    const int n = kmax+4;
+    const TF* __restrict__ m1 = W + 0*(size_t)n*ncol + col; const TF* __restrict__ m2 = W + 1*(size_t)n*ncol + col;
+    const TF* __restrict__ m3 = W + 2*(size_t)n*ncol + col; const TF* __restrict__ m4 = W + 3*(size_t)n*ncol + col;
+    const TF* __restrict__ m5 = W + 4*(size_t)n*ncol + col; const TF* __restrict__ m6 = W + 5*(size_t)n*ncol + col;
+    const TF* __restrict__ m7 = W + 6*(size_t)n*ncol + col;
+    TF* __restrict__ q = p + t;                                  // level l of this component at q[l*2*ncol]
+    const size_t ls = 2*ncol;
+#define A(arr, k) arr[(size_t)(k)*ncol]
+#define Q(r) q[(size_t)((r)-2)*ls]
+    // L y = q  (rows 0 and 1 carry a zero rhs)
+    TF a3 = TF(0.)*A(m3,0);
+    TF a2 = TF(0.) - a3*A(m3,1);
+    TF a1 = Q(2) - a2*A(m3,2) - a3*A(m2,2);
+    Q(2) = a1;
+    #pragma unroll 4
+    for (int k=3; k<kmax+2; ++k)
     {
-        const C2<TF> a1 = A(q,k-1), a2 = A(q,k-2), a3 = A(q,k-3); C2<TF> v = A(q,k);
-        v.x = v.x - a1.x*A(m3,k) - a2.x*A(m2,k) - a3.x*A(m1,k);
-        v.y = v.y - a1.y*A(m3,k) - a2.y*A(m2,k) - a3.y*A(m1,k);
-        A(q,k) = v;
+        const TF v = Q(k) - a1*A(m3,k) - a2*A(m2,k) - a3*A(m1,k);
+        Q(k) = v;
+        a3 = a2; a2 = a1; a1 = v;
     }
+    TF yt0, yt1;                                                 // rows kmax+2, kmax+3
+    { int k = kmax+2; yt0 = TF(0.) - a1*A(m3,k) - a2*A(m2,k) - a3*A(m1,k); a3 = a2; a2 = a1; a1 = yt0;
+      k = kmax+3;     yt1 = TF(0.) - a1*A(m3,k) - a2*A(m2,k) - a3*A(m1,k); }
     // U x = y
-    k = kmax+3;
-    { C2<TF> v0 = A(q,k), v1 = A(q,k-1), v2 = A(q,k-2);
-      v0.x = v0.x / A(m4,k); v0.y = v0.y / A(m4,k);
-      v1.x = ( v1.x - v0.x*A(m5,k-1) ) / A(m4,k-1); v1.y = ( v1.y - v0.y*A(m5,k-1) ) / A(m4,k-1);
-      v2.x = ( v2.x - v1.x*A(m5,k-2) - v0.x*A(m6,k-2) ) / A(m4,k-2); v2.y = ( v2.y - v1.y*A(m5,k-2) - v0.y*A(m6,k-2) ) / A(m4,k-2);
-      A(q,k) = v0; A(q,k-1) = v1; A(q,k-2) = v2; }
-    for (k=kmax; k>=0; --k)
+    int k = kmax+3;
+    TF b3 = yt1 / A(m4,k);
+    TF b2 = ( yt0 - b3*A(m5,k-1) ) / A(m4,k-1);
+    TF b1 = ( Q(k-2) - b2*A(m5,k-2) - b3*A(m6,k-2) ) / A(m4,k-2);
+    Q(k-2) = b1;
+    #pragma unroll 4
+    for (k=kmax; k>=2; --k)
     {
-        const C2<TF> b1 = A(q,k+1), b2 = A(q,k+2), b3 = A(q,k+3); C2<TF> v = A(q,k);
-        v.x = ( v.x - b1.x*A(m5,k) - b2.x*A(m6,k) - b3.x*A(m7,k) ) / A(m4,k);
-        v.y = ( v.y - b1.y*A(m5,k) - b2.y*A(m6,k) - b3.y*A(m7,k) ) / A(m4,k);
-        A(q,k) = v;
+        const TF v = ( Q(k) - b1*A(m5,k) - b2*A(m6,k) - b3*A(m7,k) ) / A(m4,k);
+        Q(k) = v;
+        b3 = b2; b2 = b1; b1 = v;
     }
-    for (k=0; k<kmax; ++k) p[col + (size_t)k*ncol] = A(q,k+2);
+#undef Q
 #undef A
 }
 
@@ -468,14 +506,10 @@ MHH_API int mhh_pres_solve(mhh_pres_plan* P, const mhh_grid* g, const mhh_fields
     }
     else
     {
-        if (g->dtype == MHH_F64)
-            hipLaunchKernelGGL(hdma_kernel<double>, grid, dim3(64), 0, st, (C2<double>*)P->spec, (double*)P->work, cp<double>(P->bmati), cp<double>(P->bmatj),
-                               cp<double>(P->m[0]), cp<double>(P->m[1]), cp<double>(P->m[2]), cp<double>(P->m[3]), cp<double>(P->m[4]), cp<double>(P->m[5]), cp<double>(P->m[6]),
-                               P->nxh, P->jtot, P->ktot);
-        else
-            hipLaunchKernelGGL(hdma_kernel<float>, grid, dim3(64), 0, st, (C2<float>*)P->spec, (float*)P->work, cp<float>(P->bmati), cp<float>(P->bmatj),
-                               cp<float>(P->m[0]), cp<float>(P->m[1]), cp<float>(P->m[2]), cp<float>(P->m[3]), cp<float>(P->m[4]), cp<float>(P->m[5]), cp<float>(P->m[6]),
-                               P->nxh, P->jtot, P->ktot);
+        const size_t ncol = (size_t)P->nxh*P->jtot;
+        dim3 sg((unsigned)((2*ncol + 127)/128));
+        if (g->dtype == MHH_F64) hipLaunchKernelGGL(hdma_solve_kernel<double>, sg, dim3(128), 0, st, (double*)P->spec, cp<double>(P->work), ncol, P->ktot);
+        else                     hipLaunchKernelGGL(hdma_solve_kernel<float>,  sg, dim3(128), 0, st, (float*)P->spec,  cp<float>(P->work),  ncol, P->ktot);
     }
     MHH_LAUNCH_CHECK();
     void* in2[1] = {P->spec}; void* out2[1] = {p_packed};
