@@ -101,6 +101,7 @@ typedef struct mhh_fields
     const void* s_fluxbot[MHH_MAX_SCALARS]; const void* s_fluxtop[MHH_MAX_SCALARS];
     const void* dudz; const void* dvdz; const void* dbdz;   /* boundary.get_dudz() etc.    */
     const void* z0m;
+    int   s_fluxlimit[MHH_MAX_SCALARS];   /* scalar is in advec.fluxlimit_list (src/advec_2i5.cxx:39,921) */
 } mhh_fields;
 
 const char* mhh_last_error(void);
@@ -127,6 +128,10 @@ int mhh_advec_w(const mhh_grid* g, int scheme, void* wt, const void* u, const vo
                 const void* rhoref, const void* rhorefh, void* stream);
 int mhh_advec_s(const mhh_grid* g, int scheme, void* st, const void* s, const void* u, const void* v, const void* w,
                 const void* rhoref, const void* rhorefh, void* stream);
+/* Koren-limited scalar advection, Advec_monotonic::advec_s_lim (include/advec_monotonic.h:79-180),
+ * used by Advec_2i5::exec for the scalars in fluxlimit_list (src/advec_2i5.cxx:1030). */
+int mhh_advec_s_lim(const mhh_grid* g, void* st, const void* s, const void* u, const void* v, const void* w,
+                    const void* rhoref, const void* rhorefh, void* stream);
 /* Advec::exec (src/advec_2.cxx:297-335, advec_2i5.cxx:977-1044, advec_4.cxx:592-650) */
 int mhh_advec_exec(const mhh_grid* g, int scheme, const mhh_fields* f, void* stream);
 /* calc_cfl + Master::max + *dt  (src/advec_2.cxx:51-78, advec_2i5.cxx:60-148, advec_4.cxx:51-86);

@@ -23,7 +23,8 @@ class MhhFields(C.Structure):
                 ("evisc", vp), ("p", vp), ("rhoref", vp), ("rhorefh", vp), ("visc", cd),
                 ("u_fluxbot", vp), ("u_fluxtop", vp), ("v_fluxbot", vp), ("v_fluxtop", vp),
                 ("s_fluxbot", vp * MAX_SCALARS), ("s_fluxtop", vp * MAX_SCALARS),
-                ("dudz", vp), ("dvdz", vp), ("dbdz", vp), ("z0m", vp)]
+                ("dudz", vp), ("dvdz", vp), ("dbdz", vp), ("z0m", vp),
+                ("s_fluxlimit", ci * MAX_SCALARS)]
 
 
 class MhhDiffParams(C.Structure):
@@ -46,6 +47,7 @@ SIGNATURES = {
     "mhh_advec_v": (ci, [GP, ci, vp, vp, vp, vp, vp, vp, vp]),
     "mhh_advec_w": (ci, [GP, ci, vp, vp, vp, vp, vp, vp, vp]),
     "mhh_advec_s": (ci, [GP, ci, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "mhh_advec_s_lim": (ci, [GP, vp, vp, vp, vp, vp, vp, vp, vp]),
     "mhh_advec_exec": (ci, [GP, ci, FP, vp]),
     "mhh_advec_cfl": (ci, [GP, ci, vp, vp, vp, cd, vp, C.POINTER(cd), vp]),
     "mhh_diff_c": (ci, [GP, ci, vp, vp, cd, vp]),

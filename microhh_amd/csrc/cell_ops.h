@@ -150,6 +150,48 @@ MHH_HD TF advec25_ver(const TF* __restrict__ f, int c, int kk, int ot, int ob, T
 }
 
 // =======================================================================================================
+// Koren (1993) flux-limited scalar advection (include/advec_monotonic.h:10-180, selected per scalar by
+// advec.fluxlimit_list, src/advec_2i5.cxx:921,1030). face = 0: interior face, 1: first face above the bottom wall
+// (upwind value for upward flow), 2: last face below the top wall (upwind value for downward flow).
+// =======================================================================================================
+MHH_HD double tcopysign1(double d) { return __builtin_copysign(1., d); }
+MHH_HD float  tcopysign1(float d)  { return __builtin_copysignf(1.f, d); }
+template<class TF> MHH_HD TF teps();
+template<> MHH_HD double teps<double>() { return 2.220446049250313e-16; }
+template<> MHH_HD float  teps<float>()  { return 1.1920928955078125e-07f; }
+template<class TF>
+MHH_HD TF koren_upwind(TF vel, TF far, TF near_, TF across)          // vel * (near + phi/2 * (near - far)), r from across-near
+{
+    const TF d = near_ - far;
+    const TF denom = tcopysign1(d) * tmax(tabs(d), teps<TF>());
+    const TF two_r = TF(2.) * (across - near_) / denom;
+    const TF phi = tmax(TF(0.), tmin(two_r, tmin(TF(1./3.)*(TF(1.)+two_r), TF(2.))));
+    return vel*(near_ + TF(0.5)*phi*(near_ - far));
+}
+template<class TF>
+MHH_HD TF koren_flux(int face, TF vel, TF sm2, TF sm1, TF sp1, TF sp2)
+{
+    if (vel >= TF(0.)) return (face == 1) ? vel*sm1 : koren_upwind(vel, sm2, sm1, sp1);
+    return (face == 2) ? vel*sp1 : koren_upwind(vel, sp2, sp1, sm1);
+}
+// increment of st at cell c; lev: 0 interior, 1 kstart, 2 kstart+1, 3 kend-2, 4 kend-1
+template<class TF>
+MHH_HD TF advec_s_lim_cell(const TF* __restrict__ s, const TF* __restrict__ u, const TF* __restrict__ v, const TF* __restrict__ w,
+                           int c, int jj, int kk, int lev, TF dxi, TF dyi, TF rt, TF rb, TF rc, TF dz)
+{
+    const TF xm2 = s[c-2], xm1 = s[c-1], s0 = s[c], xp1 = s[c+1], xp2 = s[c+2];
+    const TF ym2 = s[c-2*jj], ym1 = s[c-jj], yp1 = s[c+jj], yp2 = s[c+2*jj];
+    const TF hor = - ( koren_flux(0, u[c+1],  xm1, s0, xp1, xp2) - koren_flux(0, u[c], xm2, xm1, s0, xp1) ) * dxi
+                   - ( koren_flux(0, v[c+jj], ym1, s0, yp1, yp2) - koren_flux(0, v[c], ym2, ym1, s0, yp1) ) * dyi;
+    const TF zm1 = s[c-kk], zp1 = s[c+kk];
+    if (lev == 1) return hor - ( rt * koren_flux(1, w[c+kk], zm1, s0, zp1, s[c+2*kk]) ) / rc * dz;
+    if (lev == 4) return hor - ( - rb * koren_flux(2, w[c], s[c-2*kk], zm1, s0, zp1) ) / rc * dz;
+    const TF zm2 = s[c-2*kk], zp2 = s[c+2*kk];
+    return hor - ( rt * koren_flux(lev == 3 ? 2 : 0, w[c+kk], zm1, s0, zp1, zp2)
+                 - rb * koren_flux(lev == 2 ? 1 : 0, w[c],    zm2, zm1, s0, zp1) ) / rc * dz;
+}
+
+// =======================================================================================================
 // advec_4 (src/advec_4.cxx:88-486): three separate decrements (x, y if dim3, z); returns them through d[3].
 // sd = staggering stride of the advected momentum component (1, jj, kk); is_w selects the w equation, whose
 // vertical advecting velocity is the advected field itself incl. the biased wall forms.

@@ -370,6 +370,8 @@ MHH_API int mhh_rhs_exec(const mhh_grid* g, int advec_scheme, int diff_scheme, c
     MHH_REQUIRE(f->nscalars >= 0 && f->nscalars <= MHH_MAX_SCALARS, "nscalars");
     for (int n=0; n<f->nscalars; ++n) MHH_REQUIRE(f->s[n] && f->st[n], "null scalar");
     hipStream_t st = as_stream(stream);
+    if (advec_scheme != MHH_ADVEC_2I5)
+        for (int n=0; n<f->nscalars; ++n) MHH_REQUIRE(!f->s_fluxlimit[n], "fluxlimit_list is an advec_2i5 option (src/advec_2i5.cxx:39)");
     if (advec_scheme == MHH_ADVEC_2 && diff_scheme == MHH_DIFF_2)
     {
         MHH_REQUIRE(f->rhoref && f->rhorefh && g->igc >= 1 && g->jgc >= 1 && g->kgc >= 1, "advec_2+diff_2 inputs");
@@ -389,12 +391,22 @@ MHH_API int mhh_rhs_exec(const mhh_grid* g, int advec_scheme, int diff_scheme, c
         // default: the k-marching LDS kernel (k_march.hip) for u, v, w and scalar 0; further scalars take the
         // per-field kernels. MHH_RHS25_IMPL=cell selects the one-thread-per-cell fused kernel (A/B measurements).
         static const bool use_cell = [] { const char* e = getenv("MHH_RHS25_IMPL"); return e && !strcmp(e, "cell"); }();
-        if (!use_cell)
+        bool any_lim = false;
+        for (int n=0; n<f->nscalars; ++n) any_lim = any_lim || f->s_fluxlimit[n];
+        if (!use_cell || any_lim)
         {
-            if (int e = mhh_rhs25_march(g, f, p, stream)) return e;
-            for (int n=1; n<f->nscalars; ++n)
+            // a flux-limited scalar 0 (advec.fluxlimit_list, src/advec_2i5.cxx:921) leaves the fused kernel to u, v, w
+            int first = 1;
+            if (f->nscalars > 0 && f->s_fluxlimit[0])
             {
-                if (int e = mhh_advec_s(g, MHH_ADVEC_2I5, f->st[n], f->s[n], f->u, f->v, f->w, f->rhoref, f->rhorefh, stream)) return e;
+                mhh_fields fm = *f; fm.nscalars = 0; first = 0;
+                if (int e = mhh_rhs25_march(g, &fm, p, stream)) return e;
+            }
+            else if (int e = mhh_rhs25_march(g, f, p, stream)) return e;
+            for (int n=first; n<f->nscalars; ++n)
+            {
+                if (f->s_fluxlimit[n]) { if (int e = mhh_advec_s_lim(g, f->st[n], f->s[n], f->u, f->v, f->w, f->rhoref, f->rhorefh, stream)) return e; }
+                else if (int e = mhh_advec_s(g, MHH_ADVEC_2I5, f->st[n], f->s[n], f->u, f->v, f->w, f->rhoref, f->rhorefh, stream)) return e;
                 if (int e = mhh_smag2_diff_c(g, p->surface_model, f->st[n], f->s[n], f->evisc, f->s_fluxbot[n], f->s_fluxtop[n], f->rhoref, f->rhorefh, p->tPr, f->svisc[n], stream)) return e;
             }
             return MHH_OK;

@@ -206,6 +206,30 @@ MHH_API int mhh_advec_w(const mhh_grid* g, int scheme, void* wt, const void* u, 
 MHH_API int mhh_advec_s(const mhh_grid* g, int scheme, void* st, const void* sc, const void* u, const void* v, const void* w, const void* r, const void* rh, void* s)
 { return advec_any(g, scheme, 3, st, sc, u, v, w, r, rh, s); }
 
+// flux-limited scalar advection (include/advec_monotonic.h:79-180)
+template<class TF>
+struct AdvecSLimOp
+{
+    GridDev<TF> g; TF* __restrict__ t; const TF* __restrict__ s;
+    const TF* __restrict__ u; const TF* __restrict__ v; const TF* __restrict__ w;
+    const TF* __restrict__ rhoref; const TF* __restrict__ rhorefh;
+    __device__ void operator()(int, int, int k, int c) const
+    {
+        const int lev = (k == g.kstart) ? 1 : (k == g.kstart+1) ? 2 : (k == g.kend-2) ? 3 : (k == g.kend-1) ? 4 : 0;
+        t[c] += advec_s_lim_cell(s, u, v, w, c, g.icells, g.ijcells, lev, g.dxi_t, g.dyi_t, rhorefh[k+1], rhorefh[k], rhoref[k], g.dzi[k]);
+    }
+};
+MHH_API int mhh_advec_s_lim(const mhh_grid* g, void* st, const void* sc, const void* u, const void* v, const void* w, const void* r, const void* rh, void* stream)
+{
+    if (int e = check_grid(g)) return e;
+    MHH_REQUIRE(st && sc && u && v && w && r && rh, "null field");
+    MHH_REQUIRE(g->igc >= 2 && g->jgc >= 2 && g->kgc >= 1 && g->ktot >= 4, "advec_s_lim needs 2 horizontal ghost cells, 1 vertical, ktot >= 4");
+#define CALL(TF) [&]{ AdvecSLimOp<TF> op{make_grid<TF>(g), mp<TF>(st), cp<TF>(sc), cp<TF>(u), cp<TF>(v), cp<TF>(w), cp<TF>(r), cp<TF>(rh)}; \
+        return launch_interior(as_stream(stream), op.g, g->kstart, g->kend, op); }()
+    return MHH_DISPATCH(g, CALL);
+#undef CALL
+}
+
 MHH_API int mhh_advec_exec(const mhh_grid* g, int scheme, const mhh_fields* f, void* stream)
 {
     MHH_REQUIRE(f != nullptr, "fields");
@@ -214,7 +238,14 @@ MHH_API int mhh_advec_exec(const mhh_grid* g, int scheme, const mhh_fields* f, v
     if (int e = mhh_advec_v(g, scheme, f->vt, f->u, f->v, f->w, f->rhoref, f->rhorefh, stream)) return e;
     if (int e = mhh_advec_w(g, scheme, f->wt, f->u, f->v, f->w, f->rhoref, f->rhorefh, stream)) return e;
     for (int n=0; n<f->nscalars; ++n)
-        if (int e = mhh_advec_s(g, scheme, f->st[n], f->s[n], f->u, f->v, f->w, f->rhoref, f->rhorefh, stream)) return e;
+    {
+        if (f->s_fluxlimit[n])
+        {
+            MHH_REQUIRE(scheme == MHH_ADVEC_2I5, "fluxlimit_list is an advec_2i5 option (src/advec_2i5.cxx:39)");
+            if (int e = mhh_advec_s_lim(g, f->st[n], f->s[n], f->u, f->v, f->w, f->rhoref, f->rhorefh, stream)) return e;
+        }
+        else if (int e = mhh_advec_s(g, scheme, f->st[n], f->s[n], f->u, f->v, f->w, f->rhoref, f->rhorefh, stream)) return e;
+    }
     return MHH_OK;
 }
 

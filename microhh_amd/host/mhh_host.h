@@ -151,24 +151,42 @@ template<typename TF>
 class Advec
 {
     public:
-        Advec(Grid<TF>& gridin, Fields<TF>& fieldsin, int schemein, double cflmaxin = 1.0) :
-            grid(gridin), fields(fieldsin), scheme(schemein), cflmax(cflmaxin), cflmin(1.e-5), work(nullptr) {}
+        Advec(Grid<TF>& gridin, Fields<TF>& fieldsin, int schemein, double cflmaxin = 1.0, std::vector<std::string> fluxlimit_listin = {}) :
+            fluxlimit_list(std::move(fluxlimit_listin)), grid(gridin), fields(fieldsin), scheme(schemein), cflmax(cflmaxin), cflmin(1.e-5), work(nullptr)
+        {
+            // src/advec_2i5.cxx:39-45: the limited scalars need a second vertical ghost level
+            if (!fluxlimit_list.empty() && scheme != MHH_ADVEC_2I5) throw std::runtime_error("fluxlimit_list is an option of swadvec=2i5");
+            if (!fluxlimit_list.empty() && grid.get_grid_data().kgc < 2) throw std::runtime_error("fluxlimit_list needs kgc >= 2");
+        }
         virtual ~Advec() {}
         // swadvec as in src/advec.cxx:55-83
-        static std::shared_ptr<Advec> factory(Grid<TF>& g, Fields<TF>& f, const std::string& swadvec, double cflmax = 1.0)
+        static std::shared_ptr<Advec> factory(Grid<TF>& g, Fields<TF>& f, const std::string& swadvec, double cflmax = 1.0,
+                                              std::vector<std::string> fluxlimit_list = {})
         {
             int s;
             if (swadvec == "2") s = MHH_ADVEC_2; else if (swadvec == "2i5") s = MHH_ADVEC_2I5; else if (swadvec == "4") s = MHH_ADVEC_4;
             else throw std::runtime_error("\"" + swadvec + "\" is an illegal value for swadvec");
-            return std::make_shared<Advec>(g, f, s, cflmax);
+            return std::make_shared<Advec>(g, f, s, cflmax, std::move(fluxlimit_list));
         }
         void set_reduce_workspace(void* device_scratch) { work = device_scratch; }   // >= mhh_reduce_work_bytes()
         void create(Stats&) {}
         void exec(Stats&, void* stream = nullptr)
         {
-            mhh_grid g = grid.abi(); mhh_fields f = abi_fields(fields);
+            mhh_grid g = grid.abi(); mhh_fields f = abi_fields(fields); mark_limited(f);
             mhh_check(mhh_advec_exec(&g, scheme, &f, stream));
         }
+        // scalars named in advec.fluxlimit_list (src/advec_2i5.cxx:921)
+        void mark_limited(mhh_fields& f) const
+        {
+            for (const std::string& nm : fluxlimit_list)
+            {
+                const int n = scalar_index(fields, nm);
+                if (n < 0) throw std::runtime_error("fluxlimit_list: \"" + nm + "\" is not a prognostic scalar");
+                f.s_fluxlimit[n] = 1;
+            }
+        }
+        int get_scheme() const { return scheme; }
+        std::vector<std::string> fluxlimit_list;
         double get_cfl(double dt, void* stream = nullptr)
         {
             mhh_grid g = grid.abi(); double cfl = 0;
@@ -235,6 +253,22 @@ class Diff
         {
             mhh_grid g = grid.abi(); mhh_fields f = abi_fields(fields, &boundary); mhh_diff_params p = params(nullptr);
             mhh_check(mhh_diff_exec(&g, scheme, &f, &p, stream));
+        }
+        int get_scheme() const { return scheme; }
+        // advec->exec + diff->exec of Model::exec (src/model.cxx:388-392) as ONE pass over the fields where the library
+        // has a fused kernel for the scheme pair: (2,2), (2i5,smag2). The 4th-order pair stays two calls because the
+        // reference switches the w ghost cells between them (Boundary_w_type, src/model.cxx:387,389).
+        void exec_with_advec(Advec<TF>& advec, Stats& stats, void* stream = nullptr)
+        {
+            const int a = advec.get_scheme();
+            if (!((a == MHH_ADVEC_2 && scheme == MHH_DIFF_2) || (a == MHH_ADVEC_2I5 && scheme == MHH_DIFF_SMAG2)))
+            {
+                advec.exec(stats, stream); exec(stats, stream);
+                return;
+            }
+            mhh_grid g = grid.abi(); mhh_fields f = abi_fields(fields, &boundary); mhh_diff_params p = params(nullptr);
+            advec.mark_limited(f);
+            mhh_check(mhh_rhs_exec(&g, a, scheme, &f, &p, stream));
         }
         double get_dn(double dt, void* stream = nullptr)
         {

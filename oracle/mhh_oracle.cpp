@@ -23,6 +23,7 @@
 #include <cstring>
 #include <vector>
 #include <algorithm>
+#include <limits>
 #include "../include/mhh_hip.h"
 
 #define ORC_API extern "C" __attribute__((visibility("default")))
@@ -1424,6 +1425,57 @@ static void advec_s_t(const mhh_grid& g, int scheme, void* t, const void* s, con
 }
 ORC_API void orc_advec_s(const mhh_grid* g, int scheme, void* t, const void* s, const void* u, const void* v, const void* w, const void* r, const void* rh)
 { DISPATCH(g, advec_s_t<double>(*g, scheme, t,s,u,v,w,r,rh), advec_s_t<float>(*g, scheme, t,s,u,v,w,r,rh)); }
+
+// -------------------------------------------------------------------------------------------------------
+// Flux-limited scalar advection: Advec_monotonic::advec_s_lim (include/advec_monotonic.h:79-180) with the Koren
+// (1993) limiter flux_lim / flux_lim_bot / flux_lim_top (:10-77). Restated as one sweep with a per-level choice of
+// the vertical face forms; each face flux is vel * (upwind value + phi/2 * upwind difference).
+// -------------------------------------------------------------------------------------------------------
+template<class TF>
+static TF koren(TF vel, TF a, TF b, TF c, TF d, bool wall_below, bool wall_above)
+{
+    // stencil a b | c d around the face; flow from b to c when vel >= 0
+    const TF eps = std::numeric_limits<TF>::epsilon();
+    TF up, upup, down;
+    if (vel >= TF(0.)) { if (wall_below) return vel*b; up = b; upup = a; down = c; }
+    else               { if (wall_above) return vel*c; up = c; upup = d; down = b; }
+    const TF diff = up - upup;
+    const TF denom = TF(std::copysign(1., (double)diff)) * std::max(std::abs(diff), eps);
+    const TF two_r = TF(2.) * (down - up) / denom;
+    const TF phi = std::max(TF(0.), std::min(two_r, std::min(TF(1./3.)*(TF(1.)+two_r), TF(2.))));
+    return vel*(up + TF(0.5)*phi*(up - upup));
+}
+template<class TF>
+static void advec_s_lim(const mhh_grid& g, TF* t, const TF* s, const TF* u, const TF* v, const TF* w, const TF* rhoref, const TF* rhorefh)
+{
+    const int jj = g.icells, kk = g.ijcells;
+    const TF dxi = TF(1.)/TF(g.dx), dyi = TF(1.)/TF(g.dy);
+    const TF* dzi = P<TF>(g.dzi);
+    for (int k=g.kstart; k<g.kend; ++k)
+    {
+        const bool no_bot = (k == g.kstart), no_top = (k == g.kend-1);          // wall faces carry no flux
+        const bool bot1 = (k == g.kstart+1), top1 = (k == g.kend-2);            // faces next to a wall: one-sided
+        FOR_INTERIOR_PLANE(g)
+        {
+            const int c = i + j*jj + k*kk;
+            const TF fe = koren<TF>(u[c+1],  s[c-1],    s[c],    s[c+1],  s[c+2],    false, false);
+            const TF fw = koren<TF>(u[c],    s[c-2],    s[c-1],  s[c],    s[c+1],    false, false);
+            const TF fn = koren<TF>(v[c+jj], s[c-jj],   s[c],    s[c+jj], s[c+2*jj], false, false);
+            const TF fs = koren<TF>(v[c],    s[c-2*jj], s[c-jj], s[c],    s[c+jj],   false, false);
+            TF acc = - ( fe - fw ) * dxi - ( fn - fs ) * dyi;
+            if (no_bot)
+                acc = acc - ( rhorefh[k+1] * koren<TF>(w[c+kk], s[c-kk], s[c], s[c+kk], s[c+2*kk], true, false) ) / rhoref[k] * dzi[k];
+            else if (no_top)
+                acc = acc - ( - rhorefh[k] * koren<TF>(w[c], s[c-2*kk], s[c-kk], s[c], s[c+kk], false, true) ) / rhoref[k] * dzi[k];
+            else
+                acc = acc - ( rhorefh[k+1] * koren<TF>(w[c+kk], s[c-kk],   s[c],    s[c+kk], s[c+2*kk], false, top1)
+                            - rhorefh[k  ] * koren<TF>(w[c],    s[c-2*kk], s[c-kk], s[c],    s[c+kk],   bot1, false) ) / rhoref[k] * dzi[k];
+            t[c] += acc;
+        }
+    }
+}
+ORC_API void orc_advec_s_lim(const mhh_grid* g, void* t, const void* s, const void* u, const void* v, const void* w, const void* r, const void* rh)
+{ DISPATCH(g, advec_s_lim<double>(*g, D(t), D(s), D(u), D(v), D(w), D(r), D(rh)), advec_s_lim<float>(*g, F(t), F(s), F(u), F(v), F(w), F(r), F(rh))); }
 
 ORC_API double orc_advec_cfl(const mhh_grid* g, int scheme, const void* u, const void* v, const void* w, double dt)
 {

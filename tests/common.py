@@ -148,3 +148,12 @@ def grid_2nd(itot=16, jtot=12, ktot=10, gc=(3, 3, 1), dtype=np.float64, stretche
 
 def grid_4th(itot=16, jtot=12, ktot=12, dtype=np.float64, **kw):
     return Grid(itot, jtot, ktot, 2*np.pi, np.pi, 2., order=4, z=moser_z(ktot, 2.), dtype=dtype, **kw)
+
+
+def limiter_inputs(c, dtype):
+    """Signed velocities (both upwind branches), a scalar with plateaus (the eps-guarded denominator), and with
+    monotone as well as oscillating stretches (all pieces of the limiter function)."""
+    u, v, w = (c.u - dtype(0.5)).astype(dtype), (c.v - dtype(0.5)).astype(dtype), (c.w - dtype(0.5)).astype(dtype)
+    s = (np.round(c.s[0] * 6) / 6).astype(dtype)
+    s.flat[::7] = c.s[0].flat[::7]
+    return u, v, w, np.ascontiguousarray(s)

@@ -28,6 +28,7 @@ int main(int argc, char** argv)
         Grid<TF> grid; auto& gd = grid.gd;
         gd.itot = hdr[0]; gd.jtot = hdr[1]; gd.ktot = hdr[2]; gd.igc = hdr[3]; gd.jgc = hdr[4]; gd.kgc = hdr[5];
         const int sm = hdr[6];
+        const bool fused = hdr[7] & 1, limited = hdr[7] & 2;
         gd.imax = gd.itot; gd.jmax = gd.jtot; gd.kmax = gd.ktot;
         gd.icells = gd.itot + 2*gd.igc; gd.jcells = gd.jtot + 2*gd.jgc; gd.kcells = gd.ktot + 2*gd.kgc; gd.ijcells = gd.icells*gd.jcells; gd.ncells = gd.ijcells*gd.kcells;
         gd.istart = gd.igc; gd.jstart = gd.jgc; gd.kstart = gd.kgc; gd.iend = gd.istart + gd.itot; gd.jend = gd.jstart + gd.jtot; gd.kend = gd.kstart + gd.ktot;
@@ -59,7 +60,7 @@ int main(int argc, char** argv)
         TF* mlen0; HIPCHK(hipMalloc((void**)&mlen0, nk*sizeof(TF)));
         Stats stats;
         Boundary_cyclic<TF> boundary_cyclic(grid);
-        auto advec = Advec<TF>::factory(grid, fields, "2i5", 1.0);
+        auto advec = Advec<TF>::factory(grid, fields, "2i5", 1.0, limited ? std::vector<std::string>{"th"} : std::vector<std::string>{});
         auto diff = Diff<TF>::factory(grid, fields, boundary, "smag2");
         auto pres = Pres<TF>::factory(grid, fields, "2");
         advec->set_reduce_workspace(work); diff->set_reduce_workspace(work); pres->set_reduce_workspace(work);
@@ -72,8 +73,8 @@ int main(int argc, char** argv)
         diff->exec_viscosity(thermo);
         const double cfl = advec->get_cfl(dt);
         const double dnum = diff->get_dn(dt);
-        advec->exec(stats);
-        diff->exec(stats);
+        if (fused) diff->exec_with_advec(*advec, stats);
+        else     { advec->exec(stats); diff->exec(stats); }
         pres->exec(dt, stats);
         const double div = pres->check_divergence();
         HIPCHK(hipDeviceSynchronize());

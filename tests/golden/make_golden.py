@@ -60,6 +60,11 @@ def main():
         t = c.st[0].copy()
         R.ref_smag2_diff_c(G, sm, ptr(t), ptr(c.s[0]), ptr(c.evisc), ptr(c.s_fluxbot), ptr(c.s_fluxtop), ptr(c.rhoref), ptr(c.rhorefh), dbl(1./3.), dbl(1e-5))
         out["smag%d_st" % sm] = t[g2.interior]
+    # Koren-limited scalar advection (include/advec_monotonic.h:79-180): signed velocities, scalar with plateaus
+    ul, vl, wl, sl = cm.limiter_inputs(c, np.float64)
+    t = c.st[0].copy()
+    R.ref_advec_s_lim(G, ptr(t), ptr(sl), ptr(ul), ptr(vl), ptr(wl), ptr(c.rhoref), ptr(c.rhorefh))
+    out["advec_s_lim_st"] = t[g2.interior]
     out["smag_dnmul"] = np.array(R.ref_smag2_dnmul(G, ptr(c.evisc), dbl(1./3.)))
     # input fingerprint so that a drift of the input recipe is detected rather than misread as a kernel error
     out["fingerprint"] = np.array([c2.u.sum(), c2.rhorefh.sum(), c4.w.sum(), c2.evisc.sum()])

@@ -52,6 +52,9 @@ def test_oracle_reproduces_reference_vectors():
         t = c.st[0].copy(); O.orc_smag2_diff_c(G, sm, ptr(t), ptr(c.s[0]), ptr(c.evisc), ptr(c.s_fluxbot), ptr(c.s_fluxtop), ptr(c.rhoref), ptr(c.rhorefh), dbl(1./3.), dbl(1e-5))
         assert np.array_equal(t[g2.interior], GOLD["smag%d_st" % sm])
     assert O.orc_smag2_dnmul(G, ptr(c.evisc), dbl(1./3.)) == float(GOLD["smag_dnmul"])
+    ul, vl, wl, sl = cm.limiter_inputs(c, np.float64)
+    t = c.st[0].copy(); O.orc_advec_s_lim(G, ptr(t), ptr(sl), ptr(ul), ptr(vl), ptr(wl), ptr(c.rhoref), ptr(c.rhorefh))
+    assert np.array_equal(t[g2.interior], GOLD["advec_s_lim_st"])
 
 
 @pytest.mark.parametrize("name", [pytest.param("emul"), pytest.param("hip", marks=pytest.mark.gpu)])
@@ -87,3 +90,8 @@ def test_hip_path_reproduces_reference_vectors(name):
         t = be.arr(c.st[0])
         B.ok(be, be.lib.mhh_smag2_diff_c(d.G, sm, be.ptr(t), be.ptr(d.s[0]), be.ptr(d.evisc), be.ptr(d.s_fluxbot), be.ptr(d.s_fluxtop), be.ptr(d.rhoref), be.ptr(d.rhorefh), 1./3., 1e-5, be.stream))
         assert np.array_equal(be.host(t)[g2.interior], GOLD["smag%d_st" % sm])
+    ul, vl, wl, sl = cm.limiter_inputs(c, np.float64)
+    t = be.arr(c.st[0])
+    dl = [be.arr(x) for x in (sl, ul, vl, wl)]          # keep the device copies alive across the call
+    B.ok(be, be.lib.mhh_advec_s_lim(d.G, be.ptr(t), *[be.ptr(x) for x in dl], be.ptr(d.rhoref), be.ptr(d.rhorefh), be.stream))
+    assert np.array_equal(be.host(t)[g2.interior], GOLD["advec_s_lim_st"])

@@ -49,6 +49,23 @@ def test_advec_bitwise(scheme, refname, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_advec_s_lim_bitwise(dtype):
+    """Koren flux limiter (include/advec_monotonic.h:10-180) against the reference's own template."""
+    O = cm.oracle()
+    for g in grids2(dtype) + [cm.grid_2nd(12, 8, 8, gc=(3, 3, 2), dtype=dtype)]:
+        if g.ktot < 6:
+            continue
+        c = cm.Case(g)
+        G = g.host_struct()
+        u, v, w, s = cm.limiter_inputs(c, dtype)
+        t_o, t_r = c.st[0].copy(), c.st[0].copy()
+        O.orc_advec_s_lim(G, ptr(t_o), ptr(s), ptr(u), ptr(v), ptr(w), ptr(c.rhoref), ptr(c.rhorefh))
+        REF.ref_advec_s_lim(G, ptr(t_r), ptr(s), ptr(u), ptr(v), ptr(w), ptr(c.rhoref), ptr(c.rhorefh))
+        assert np.array_equal(t_o, t_r), ("advec_s_lim", g.shape3, cm.ulp_diff(t_o, t_r))
+        assert not np.array_equal(t_o, c.st[0])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("order", [2, 4])
 def test_diff_bitwise(order, dtype):
     O = cm.oracle()

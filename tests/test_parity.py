@@ -70,6 +70,32 @@ def test_boundary_cyclic(be, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_advec_s_lim_bitexact(be, dtype):
+    """Flux-limited scalar advection (include/advec_monotonic.h:79-180): kernel and its place in Advec::exec and the fused RHS."""
+    O = cm.oracle()
+    for g in grids2(dtype) + [cm.grid_2nd(12, 8, 8, gc=(3, 3, 2), dtype=dtype)]:
+        if g.ktot < 6:
+            continue
+        c = cm.Case(g); Gh = g.host_struct()
+        c.u, c.v, c.w, c.s[0] = cm.limiter_inputs(c, dtype)
+        d = B.DevCase(be, c)
+        want = c.st[0].copy()
+        O.orc_advec_s_lim(Gh, ptr(want), ptr(c.s[0]), ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.rhoref), ptr(c.rhorefh))
+        t = be.arr(c.st[0])
+        B.ok(be, be.lib.mhh_advec_s_lim(d.G, be.ptr(t), be.ptr(d.s[0]), be.ptr(d.u), be.ptr(d.v), be.ptr(d.w), be.ptr(d.rhoref), be.ptr(d.rhorefh), be.stream))
+        got = be.host(t)
+        assert same(got, want), ("advec_s_lim", g.shape3, cm.ulp_diff(got, want))
+        # Advec_2i5::exec with the scalar in fluxlimit_list (src/advec_2i5.cxx:921,1030)
+        f = d.fields(); f.s_fluxlimit[0] = 1
+        B.ok(be, be.lib.mhh_advec_exec(d.G, cm.ADVEC_2I5, C.byref(f), be.stream))
+        assert same(be.host(d.st[0]), want), ("advec_exec with limiter", g.shape3)
+        wu = c.copy_of("ut"); O.orc_advec_u(Gh, cm.ADVEC_2I5, ptr(wu), ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.rhoref), ptr(c.rhorefh))
+        assert same(be.host(d.ut), wu)
+        # the limiter belongs to advec_2i5 only
+        assert be.lib.mhh_advec_exec(d.G, cm.ADVEC_2, C.byref(f), be.stream) != 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("scheme", [cm.ADVEC_2, cm.ADVEC_2I5, cm.ADVEC_4])
 def test_advec_kernels_bitexact(be, scheme, dtype):
     O = cm.oracle()
@@ -165,14 +191,17 @@ def test_smag2_kernels(be, sm, dtype):
         assert same(be.host(n2), w_)
 
 
-def _oracle_rhs(c, adv, dif, sm, tPr=1./3., visc=1e-5, svisc=1e-5):
+def _oracle_rhs(c, adv, dif, sm, tPr=1./3., visc=1e-5, svisc=1e-5, limited=()):
     """Advec::exec followed by Diff::exec on the oracle; returns the tendencies."""
     O = cm.oracle(); g = c.grid; Gh = g.host_struct()
     ut, vt, wt, st = c.ut.copy(), c.vt.copy(), c.wt.copy(), [x.copy() for x in c.st]
     a = (ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.rhoref), ptr(c.rhorefh))
     O.orc_advec_u(Gh, adv, ptr(ut), *a); O.orc_advec_v(Gh, adv, ptr(vt), *a); O.orc_advec_w(Gh, adv, ptr(wt), *a)
     for n in range(len(st)):
-        O.orc_advec_s(Gh, adv, ptr(st[n]), ptr(c.s[n]), *a)
+        if n in limited:
+            O.orc_advec_s_lim(Gh, ptr(st[n]), ptr(c.s[n]), *a)
+        else:
+            O.orc_advec_s(Gh, adv, ptr(st[n]), ptr(c.s[n]), *a)
     if dif in (cm.DIFF_2, cm.DIFF_4):
         o = 2 if dif == cm.DIFF_2 else 4
         O.orc_diff_c(Gh, o, ptr(ut), ptr(c.u), dbl(visc)); O.orc_diff_c(Gh, o, ptr(vt), ptr(c.v), dbl(visc)); O.orc_diff_w(Gh, o, ptr(wt), ptr(c.w), dbl(visc))
@@ -215,6 +244,35 @@ def test_operator_exec_and_fused_rhs_bitexact(be, adv, dif, sm, dtype):
                 assert same(a, b), ("fused", nm, adv, dif, g.shape3, cm.ulp_diff(a, b))
             for a, b in zip(got[3], want[3]):
                 assert same(a, b), ("fused s", adv, dif)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("limited", [(0,), (1,), (0, 1)])
+def test_fused_rhs_with_fluxlimit_list(be, limited, dtype):
+    """advec.fluxlimit_list (src/advec_2i5.cxx:39,921): the listed scalars take the Koren-limited scheme inside
+    mhh_rhs_exec and mhh_advec_exec + mhh_diff_exec; everything else keeps the 2i5 bits."""
+    adv, dif, sm = cm.ADVEC_2I5, cm.DIFF_SMAG2, 1
+    for g in grids2(dtype)[:2]:
+        c = cm.Case(g, nscalars=2)
+        c.u, c.v, c.w, c.s[0] = cm.limiter_inputs(c, dtype)
+        want = _oracle_rhs(c, adv, dif, sm, limited=limited)
+        p = capi.MhhDiffParams(); p.cs = 0.23; p.tPr = 1./3.; p.surface_model = sm
+        for fused in (False, True):
+            d = B.DevCase(be, c); f = d.fields()
+            for n in limited:
+                f.s_fluxlimit[n] = 1
+            if fused:
+                B.ok(be, be.lib.mhh_rhs_exec(d.G, adv, dif, C.byref(f), C.byref(p), be.stream))
+            else:
+                B.ok(be, be.lib.mhh_advec_exec(d.G, adv, C.byref(f), be.stream))
+                B.ok(be, be.lib.mhh_diff_exec(d.G, dif, C.byref(f), C.byref(p), be.stream))
+            got = (be.host(d.ut), be.host(d.vt), be.host(d.wt), [be.host(x) for x in d.st])
+            for a, b, nm in zip(got[:3], want[:3], "uvw"):
+                assert same(a, b), (fused, nm, g.shape3, cm.ulp_diff(a, b))
+            for n, (a, b) in enumerate(zip(got[3], want[3])):
+                assert same(a, b), (fused, "s%d" % n, limited, g.shape3, cm.ulp_diff(a, b))
+        f = d.fields(); f.s_fluxlimit[0] = 1
+        assert be.lib.mhh_rhs_exec(d.G, cm.ADVEC_2, cm.DIFF_2, C.byref(f), C.byref(p), be.stream) != 0
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
