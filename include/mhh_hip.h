@@ -190,9 +190,18 @@ typedef struct mhh_diff_params
     const void* thref;       /* [kcells]                                                   */
     double grav;
     const void* mlen0;       /* [kcells] device table from mhh_smag2_mlen0_host            */
+    /* dry buoyancy folded into mhh_rhs_exec (Thermo_dry::exec precedes Advec::exec in Model::exec,
+     * src/model.cxx:365,388): wt += grav/threfh[k]*(th_h - threfh[k]) for scalar th_for_N2, first. */
+    int    buoyancy;         /* 0 = off, 2 / 4 = interpolation order (swspatialorder)      */
+    const void* threfh;      /* [kcells]                                                   */
 } mhh_diff_params;
 int mhh_diff_exec_viscosity(const mhh_grid* g, int scheme, const mhh_fields* f, const mhh_diff_params* p, void* stream);
 int mhh_diff_exec(const mhh_grid* g, int scheme, const mhh_fields* f, const mhh_diff_params* p, void* stream);
+
+/* Thermo_dry::exec buoyancy tendency, calc_buoyancy_tend_2nd / _4th (src/thermo_dry.cxx:165-197,
+ * GPU src/thermo_dry.cu): wt[k] += grav/threfh[k]*(interp(th) - threfh[k]) for k in (kstart, kend). */
+int mhh_thermo_dry_buoyancy_tend(const mhh_grid* g, int order, void* wt, const void* th, const void* threfh,
+                                 double grav, void* stream);
 
 /* ---- Fused RHS: advec.exec + diff.exec in one pass over the tendencies ------------------
  * Same arithmetic, same order of accumulation into each tendency as calling

@@ -29,7 +29,8 @@ class MhhFields(C.Structure):
 
 class MhhDiffParams(C.Structure):
     _fields_ = [("cs", cd), ("tPr", cd), ("surface_model", ci), ("neutral", ci), ("N2", vp),
-                ("th_for_N2", ci), ("thref", vp), ("grav", cd), ("mlen0", vp)]
+                ("th_for_N2", ci), ("thref", vp), ("grav", cd), ("mlen0", vp),
+                ("buoyancy", ci), ("threfh", vp)]
 
 
 FP = C.POINTER(MhhFields)
@@ -49,6 +50,7 @@ SIGNATURES = {
     "mhh_advec_s": (ci, [GP, ci, vp, vp, vp, vp, vp, vp, vp, vp]),
     "mhh_advec_s_lim": (ci, [GP, vp, vp, vp, vp, vp, vp, vp, vp]),
     "mhh_advec_exec": (ci, [GP, ci, FP, vp]),
+    "mhh_thermo_dry_buoyancy_tend": (ci, [GP, ci, vp, vp, vp, cd, vp]),
     "mhh_advec_cfl": (ci, [GP, ci, vp, vp, vp, cd, vp, C.POINTER(cd), vp]),
     "mhh_diff_c": (ci, [GP, ci, vp, vp, cd, vp]),
     "mhh_diff_w": (ci, [GP, ci, vp, vp, cd, vp]),

@@ -149,6 +149,14 @@ MHH_HD TF advec25_ver(const TF* __restrict__ f, int c, int kk, int ot, int ob, T
     return cen;
 }
 
+// Thermo_dry buoyancy tendency of w (src/thermo_dry.cxx:165-197): grav/threfh[k] * (th at the w level - threfh[k])
+template<class TF>
+MHH_HD TF buoyancy_tend(const TF* __restrict__ th, int c, int kk, int order, TF grav, TF threfh_k)
+{
+    const TF thh = (order == 4) ? i4c(th[c-2*kk], th[c-kk], th[c], th[c+kk]) : i2(th[c-kk], th[c]);
+    return grav/threfh_k * (thh - threfh_k);
+}
+
 // =======================================================================================================
 // Koren (1993) flux-limited scalar advection (include/advec_monotonic.h:10-180, selected per scalar by
 // advec.fluxlimit_list, src/advec_2i5.cxx:921,1030). face = 0: interior face, 1: first face above the bottom wall

@@ -71,6 +71,7 @@ template<class TF> struct MarchFields
     const TF* __restrict__ ufb; const TF* __restrict__ uft; const TF* __restrict__ vfb; const TF* __restrict__ vft;
     const TF* __restrict__ sfb; const TF* __restrict__ sft;
     TF visc, svisc, tPr; int sm;
+    const TF* __restrict__ threfh; TF grav;      // folded dry buoyancy of the scalar (threfh == nullptr: off)
 };
 
 struct MarchTiling { int nbx, nby, nkc, sr, ns, kc; };
@@ -384,6 +385,7 @@ __global__ void __launch_bounds__(64*NJ, MHH_MARCH_OCC) rhs25_march_kernel(const
                 const TF ue = i2(ukm[1], uk[1]), uwf = i2(ukm[0], uk[0]);
                 const TF vn = i2(vkm[TI], vk[TI]), vs = i2(vkm[0], vk[0]);
                 TF t = f.wt[c];
+                if (HAS_S && f.threfh) { const TF th_k = f.threfh[k]; t += f.grav/th_k * (i2(sw[2], sw[3]) - th_k); }   // src/thermo_dry.cxx:165-178
                 t += advec25_hor(wk, 0, TI, ue, uwf, vn, vs, dxi, dyi);
                 t += vert_combine(otw, obw, Tw, cTw, Gw, cGw, rhk, rhk1, dzhi);
                 const TF ee = TF(0.25)*(ekm[0  ] + ek[0  ] + ekm[1 ] + ek[1 ]) + visc;
@@ -463,6 +465,8 @@ int march_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* 
     mf.ufb = cp<TF>(f->u_fluxbot); mf.uft = cp<TF>(f->u_fluxtop); mf.vfb = cp<TF>(f->v_fluxbot); mf.vft = cp<TF>(f->v_fluxtop);
     mf.sfb = has_s ? cp<TF>(f->s_fluxbot[0]) : nullptr; mf.sft = has_s ? cp<TF>(f->s_fluxtop[0]) : nullptr;
     mf.visc = TF(f->visc); mf.svisc = has_s ? TF(f->svisc[0]) : TF(0); mf.tPr = TF(p->tPr); mf.sm = p->surface_model;
+    const bool buoy = has_s && p->buoyancy == 2 && p->th_for_N2 == 0;
+    mf.threfh = buoy ? cp<TF>(p->threfh) : nullptr; mf.grav = buoy ? TF(p->grav) : TF(0);
     MarchTiling t;
     t.nbx = (g->imax + 63)/64; t.nby = (g->jmax + NJ-1)/NJ;
 #ifndef MHH_MARCH_KC

@@ -216,6 +216,7 @@ template<class TF> struct FieldsDev
     const TF* __restrict__ ev; const TF* __restrict__ rhoref; const TF* __restrict__ rhorefh;
     const TF* __restrict__ ufb; const TF* __restrict__ uft; const TF* __restrict__ vfb; const TF* __restrict__ vft;
     TF visc, tPr; int sm;
+    const TF* __restrict__ bth; const TF* __restrict__ threfh; TF grav; int border;   // folded buoyancy (bth == nullptr: off)
 };
 template<class TF>
 static FieldsDev<TF> make_fields(const mhh_fields* f, const mhh_diff_params* p)
@@ -233,6 +234,9 @@ static FieldsDev<TF> make_fields(const mhh_fields* f, const mhh_diff_params* p)
     d.ev = cp<TF>(f->evisc); d.rhoref = cp<TF>(f->rhoref); d.rhorefh = cp<TF>(f->rhorefh);
     d.ufb = cp<TF>(f->u_fluxbot); d.uft = cp<TF>(f->u_fluxtop); d.vfb = cp<TF>(f->v_fluxbot); d.vft = cp<TF>(f->v_fluxtop);
     d.visc = TF(f->visc); d.tPr = p ? TF(p->tPr) : TF(1); d.sm = p ? p->surface_model : 0;
+    const bool buoy = p && p->buoyancy;
+    d.bth = buoy ? cp<TF>(f->s[p->th_for_N2]) : nullptr; d.threfh = buoy ? cp<TF>(p->threfh) : nullptr;
+    d.grav = buoy ? TF(p->grav) : TF(0); d.border = buoy ? p->buoyancy : 0;
     return d;
 }
 
@@ -259,6 +263,7 @@ struct Rhs22Op
         if (k > g.kstart)
         {
             TF t = f.wt[c];
+            if (f.bth) t += buoyancy_tend(f.bth, c, kk, f.border, f.grav, f.threfh[k]);
             t += advec2_mom(f.w, f.u, f.v, f.w, c, -kk, jj, kk, g.dxi_t, g.dyi_t, rk, f.rhoref[k-1], rhk, dzhi);
             f.wt[c] = diff2_apply(t, f.w, c, jj, kk, f.visc, g.dxidxi_2, g.dyidyi_2, dzi, g.dzi[k-1], dzhi);
         }
@@ -305,6 +310,7 @@ struct Rhs25SmagOp
             const int o = -kk;
             const TF rkm = f.rhoref[k-1];
             TF t = f.wt[c];
+            if (f.bth) t += buoyancy_tend(f.bth, c, kk, f.border, f.grav, f.threfh[k]);
             t += advec25_hor(f.w, c, jj, i2(f.u[c+1+o], f.u[c+1]), i2(f.u[c+o], f.u[c]), i2(f.v[c+jj+o], f.v[c+jj]), i2(f.v[c+o], f.v[c]), g.dxi_t, g.dyi_t);
             t += advec25_ver(f.w, c, kk, order_face_w(k, g.kstart, g.kend), order_face_w(k-1, g.kstart, g.kend),
                              i2(f.w[c+kk+o], f.w[c+kk]), i2(f.w[c+o], f.w[c]), rk, rkm, rhk, dzhi);
@@ -352,7 +358,7 @@ struct Rhs44Op
             const TF gw4[4] = {g.dzi4[k-2], g.dzi4[k-1], g.dzi4[k], g.dzi4[k+1]};
             advec4_mom(ad, f.w, f.u, f.v, f.w, c, kk, true, jj, kk, botw, top, g.dxi_t, g.dyi_t, g.dzhi4[k], g.dim3);
             diff4_cell(df, f.w, c, jj, kk, botw, top, f.visc, g.dxidxi_t, g.dyidyi_t, gw4, g.dzhi4[k], g.dim3);
-            f.wt[c] = both(f.wt[c], ad, df);
+            f.wt[c] = both(f.bth ? f.wt[c] + buoyancy_tend(f.bth, c, kk, f.border, f.grav, f.threfh[k]) : f.wt[c], ad, df);
         }
         for (int n=0; n<f.ns; ++n)
         {
@@ -370,6 +376,12 @@ MHH_API int mhh_rhs_exec(const mhh_grid* g, int advec_scheme, int diff_scheme, c
     MHH_REQUIRE(f->nscalars >= 0 && f->nscalars <= MHH_MAX_SCALARS, "nscalars");
     for (int n=0; n<f->nscalars; ++n) MHH_REQUIRE(f->s[n] && f->st[n], "null scalar");
     hipStream_t st = as_stream(stream);
+    if (p && p->buoyancy)
+    {
+        MHH_REQUIRE(p->buoyancy == 2 || p->buoyancy == 4, "buoyancy order must be 2 or 4");
+        MHH_REQUIRE(p->th_for_N2 >= 0 && p->th_for_N2 < f->nscalars && p->threfh, "buoyancy needs th_for_N2 and threfh");
+        MHH_REQUIRE(g->kgc >= (p->buoyancy == 4 ? 2 : 1), "buoyancy: vertical ghost cells");
+    }
     if (advec_scheme != MHH_ADVEC_2I5)
         for (int n=0; n<f->nscalars; ++n) MHH_REQUIRE(!f->s_fluxlimit[n], "fluxlimit_list is an advec_2i5 option (src/advec_2i5.cxx:39)");
     if (advec_scheme == MHH_ADVEC_2 && diff_scheme == MHH_DIFF_2)
@@ -395,14 +407,21 @@ MHH_API int mhh_rhs_exec(const mhh_grid* g, int advec_scheme, int diff_scheme, c
         for (int n=0; n<f->nscalars; ++n) any_lim = any_lim || f->s_fluxlimit[n];
         if (!use_cell || any_lim)
         {
+            // the march kernel folds the buoyancy of scalar 0 in (2nd order); otherwise it is added first, on its own
+            const mhh_diff_params* pm = p; mhh_diff_params pnb;
+            if (p->buoyancy && !(p->buoyancy == 2 && p->th_for_N2 == 0 && !f->s_fluxlimit[0]))
+            {
+                if (int e = mhh_thermo_dry_buoyancy_tend(g, p->buoyancy, f->wt, f->s[p->th_for_N2], p->threfh, p->grav, stream)) return e;
+                pnb = *p; pnb.buoyancy = 0; pm = &pnb;
+            }
             // a flux-limited scalar 0 (advec.fluxlimit_list, src/advec_2i5.cxx:921) leaves the fused kernel to u, v, w
             int first = 1;
             if (f->nscalars > 0 && f->s_fluxlimit[0])
             {
                 mhh_fields fm = *f; fm.nscalars = 0; first = 0;
-                if (int e = mhh_rhs25_march(g, &fm, p, stream)) return e;
+                if (int e = mhh_rhs25_march(g, &fm, pm, stream)) return e;
             }
-            else if (int e = mhh_rhs25_march(g, f, p, stream)) return e;
+            else if (int e = mhh_rhs25_march(g, f, pm, stream)) return e;
             for (int n=first; n<f->nscalars; ++n)
             {
                 if (f->s_fluxlimit[n]) { if (int e = mhh_advec_s_lim(g, f->st[n], f->s[n], f->u, f->v, f->w, f->rhoref, f->rhorefh, stream)) return e; }

@@ -515,6 +515,25 @@ MHH_API int mhh_smag2_diff_w(const mhh_grid* g, void* wt, const void* u, const v
 MHH_API int mhh_smag2_diff_c(const mhh_grid* g, int sm, void* at, const void* a, const void* ev, const void* fb, const void* ft, const void* r, const void* rh, double tPr, double visc, void* s)
 { return smag_diff_any(g, 3, sm, at, a, nullptr, nullptr, nullptr, ev, fb, ft, r, rh, visc, tPr, s); }
 
+// Thermo_dry buoyancy tendency (src/thermo_dry.cxx:165-197)
+template<class TF>
+struct BuoyancyOp
+{
+    GridDev<TF> g; int order; TF* __restrict__ wt; const TF* __restrict__ th; const TF* __restrict__ threfh; TF grav;
+    __device__ void operator()(int, int, int k, int c) const { wt[c] += buoyancy_tend(th, c, g.ijcells, order, grav, threfh[k]); }
+};
+MHH_API int mhh_thermo_dry_buoyancy_tend(const mhh_grid* g, int order, void* wt, const void* th, const void* threfh, double grav, void* stream)
+{
+    if (int e = check_grid(g)) return e;
+    MHH_REQUIRE(wt && th && threfh, "null field");
+    MHH_REQUIRE(order == 2 || order == 4, "order must be 2 or 4");
+    MHH_REQUIRE(g->kgc >= (order == 4 ? 2 : 1), "vertical ghost cells");
+#define CALL(TF) [&]{ BuoyancyOp<TF> op{make_grid<TF>(g), order, mp<TF>(wt), cp<TF>(th), cp<TF>(threfh), TF(grav)}; \
+        return launch_interior(as_stream(stream), op.g, g->kstart+1, g->kend, op); }()
+    return MHH_DISPATCH(g, CALL);
+#undef CALL
+}
+
 // Thermo_dry calc_N2 (src/thermo_dry.cxx:66-78)
 template<class TF>
 struct N2Op

@@ -95,8 +95,16 @@ struct Thermo
 {
     std::string swthermo = "0";
     TF* N2_g = nullptr;            // get_thermo_field("N2") result, or null to have it evaluated from scalar `th`
-    std::string th = "th"; TF* thref_g = nullptr; TF grav = 9.81;
+    std::string th = "th"; TF* thref_g = nullptr; TF* threfh_g = nullptr; TF grav = 9.81;
+    int swspatialorder = 2;        // grid.swspatialorder: calc_buoyancy_tend_2nd / _4th (src/thermo_dry.cxx:557-562)
     std::string get_switch() const { return swthermo; }
+    // Thermo_dry::exec (src/thermo_dry.cxx:551-565): the buoyancy tendency of w; defined after Fields/Grid below
+    template<class G, class F> void exec(G& grid, F& fields, void* stream = nullptr)
+    {
+        if (swthermo != "dry") return;
+        mhh_grid g = grid.abi();
+        mhh_check(mhh_thermo_dry_buoyancy_tend(&g, swspatialorder, fields.mt.at("w")->fld_g, fields.sp.at(th)->fld_g, threfh_g, grav, stream));
+    }
 };
 struct Stats {};                   // calc_tend is a no-op off sampling steps (src/stats.cxx:1893-1896)
 
@@ -258,15 +266,23 @@ class Diff
         // advec->exec + diff->exec of Model::exec (src/model.cxx:388-392) as ONE pass over the fields where the library
         // has a fused kernel for the scheme pair: (2,2), (2i5,smag2). The 4th-order pair stays two calls because the
         // reference switches the w ghost cells between them (Boundary_w_type, src/model.cxx:387,389).
-        void exec_with_advec(Advec<TF>& advec, Stats& stats, void* stream = nullptr)
+        // fold_buoyancy: also add Thermo_dry's buoyancy tendency (the caller then skips thermo->exec; nothing between it and
+        // advec->exec touches wt, src/model.cxx:365-388)
+        void exec_with_advec(Advec<TF>& advec, Stats& stats, void* stream = nullptr, Thermo<TF>* fold_buoyancy = nullptr)
         {
             const int a = advec.get_scheme();
             if (!((a == MHH_ADVEC_2 && scheme == MHH_DIFF_2) || (a == MHH_ADVEC_2I5 && scheme == MHH_DIFF_SMAG2)))
             {
+                if (fold_buoyancy) fold_buoyancy->exec(grid, fields, stream);
                 advec.exec(stats, stream); exec(stats, stream);
                 return;
             }
             mhh_grid g = grid.abi(); mhh_fields f = abi_fields(fields, &boundary); mhh_diff_params p = params(nullptr);
+            if (fold_buoyancy && fold_buoyancy->get_switch() == "dry")
+            {
+                p.buoyancy = fold_buoyancy->swspatialorder; p.th_for_N2 = scalar_index(fields, fold_buoyancy->th);
+                p.threfh = fold_buoyancy->threfh_g; p.grav = fold_buoyancy->grav;
+            }
             advec.mark_limited(f);
             mhh_check(mhh_rhs_exec(&g, a, scheme, &f, &p, stream));
         }

@@ -1513,6 +1513,23 @@ ORC_API double orc_smag2_dnmul(const mhh_grid* g, const void* ev, double tPr)
     if (g->dtype == MHH_F64) return smag_dnmul<double>(*g, D(ev), tPr);
     return smag_dnmul<float>(*g, F(ev), (float)tPr);
 }
+// Thermo_dry buoyancy tendency (src/thermo_dry.cxx:165-197; that TU needs netcdf.h, so this line is restated, not linked)
+template<class TF>
+static void buoyancy_tend(const mhh_grid& g, int order, TF* wt, const TF* th, const TF* threfh, TF grav)
+{
+    const int jj = g.icells, kk = g.ijcells;
+    for (int k=g.kstart+1; k<g.kend; ++k)
+        FOR_INTERIOR_PLANE(g)
+        {
+            const int c = i + j*jj + k*kk;
+            const TF thh = (order == 4) ? TF(-1./16.)*(th[c-2*kk] + th[c+kk]) + TF(9./16.)*(th[c-kk] + th[c])
+                                        : TF(0.5)*(th[c-kk] + th[c]);
+            wt[c] += grav/threfh[k] * (thh - threfh[k]);
+        }
+}
+ORC_API void orc_buoyancy_tend(const mhh_grid* g, int order, void* wt, const void* th, const void* threfh, double grav)
+{ DISPATCH(g, buoyancy_tend<double>(*g, order, D(wt), D(th), D(threfh), grav), buoyancy_tend<float>(*g, order, F(wt), F(th), F(threfh), (float)grav)); }
+
 ORC_API void orc_calc_N2(const mhh_grid* g, void* N2, const void* th, const void* thref, double grav)
 { DISPATCH(g, calc_N2<double>(*g, D(N2), D(th), D(thref), grav), calc_N2<float>(*g, F(N2), F(th), F(thref), (float)grav)); }
 

@@ -28,7 +28,7 @@ int main(int argc, char** argv)
         Grid<TF> grid; auto& gd = grid.gd;
         gd.itot = hdr[0]; gd.jtot = hdr[1]; gd.ktot = hdr[2]; gd.igc = hdr[3]; gd.jgc = hdr[4]; gd.kgc = hdr[5];
         const int sm = hdr[6];
-        const bool fused = hdr[7] & 1, limited = hdr[7] & 2;
+        const bool fused = hdr[7] & 1, limited = hdr[7] & 2, buoy = hdr[7] & 4;
         gd.imax = gd.itot; gd.jmax = gd.jtot; gd.kmax = gd.ktot;
         gd.icells = gd.itot + 2*gd.igc; gd.jcells = gd.jtot + 2*gd.jgc; gd.kcells = gd.ktot + 2*gd.kgc; gd.ijcells = gd.icells*gd.jcells; gd.ncells = gd.ijcells*gd.kcells;
         gd.istart = gd.igc; gd.jstart = gd.jgc; gd.kstart = gd.kgc; gd.iend = gd.istart + gd.itot; gd.jend = gd.jstart + gd.jtot; gd.kend = gd.kstart + gd.ktot;
@@ -53,6 +53,7 @@ int main(int argc, char** argv)
         Boundary<TF> boundary; boundary.swboundary = sm ? "surface" : "default";
         boundary.dudz_g = up(rd(in, n2)); boundary.dvdz_g = up(rd(in, n2)); boundary.dbdz_g = up(rd(in, n2)); boundary.z0m_g = up(rd(in, n2));
         Thermo<TF> thermo; thermo.swthermo = "dry"; thermo.thref_g = up(rd(in, nk)); thermo.grav = 9.81;
+        if (buoy) thermo.threfh_g = up(rd(in, nk));
         std::fclose(in);
         for (const char* nm : {"evisc", "p"}) { auto f = std::make_shared<Field3d<TF>>(); f->fld_g = up(std::vector<TF>(n3, 0.)); fields.sd[nm] = f; }
 
@@ -73,8 +74,8 @@ int main(int argc, char** argv)
         diff->exec_viscosity(thermo);
         const double cfl = advec->get_cfl(dt);
         const double dnum = diff->get_dn(dt);
-        if (fused) diff->exec_with_advec(*advec, stats);
-        else     { advec->exec(stats); diff->exec(stats); }
+        if (fused) diff->exec_with_advec(*advec, stats, nullptr, buoy ? &thermo : nullptr);
+        else     { if (buoy) thermo.exec(grid, fields); advec->exec(stats); diff->exec(stats); }
         pres->exec(dt, stats);
         const double div = pres->check_divergence();
         HIPCHK(hipDeviceSynchronize());

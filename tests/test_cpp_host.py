@@ -23,21 +23,23 @@ def test_host_header_is_self_contained():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", [0, 1, 2, 3], ids=["two-calls", "fused", "two-calls-limited", "fused-limited"])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5], ids=["two-calls", "fused", "two-calls-limited", "fused-limited", "two-calls-buoyancy", "fused-buoyancy"])
 def test_cpp_host_substep_matches_oracle(mode):
-    """mode bit 0: advec->exec + diff->exec as the fused pass; bit 1: "th" in advec.fluxlimit_list (kgc = 2)."""
+    """mode bit 0: advec->exec + diff->exec as the fused pass; bit 1: "th" in advec.fluxlimit_list (kgc = 2);
+    bit 2: Thermo_dry buoyancy (thermo->exec before advec, or folded into the fused pass)."""
     subprocess.run(["make", "-s", "-C", CPP], check=True)
     g = cm.grid_2nd(32, 24, 16, gc=(3, 3, 2 if mode & 2 else 1), stretched=False)
     c = cm.Case(g, rho="one")
     sm, dt, visc = 1, 0.6, 1e-5
     thref = np.full(g.kcells, 300.)
+    threfh = 300. + 0.37*np.arange(g.kcells)
     with tempfile.TemporaryDirectory() as tmp:
         fin, fout = os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.bin")
         with open(fin, "wb") as f:
             np.array([g.itot, g.jtot, g.ktot, g.igc, g.jgc, g.kgc, sm, mode], dtype=np.int32).tofile(f)
             np.array([g.xsize, g.ysize, g.zsize, dt, visc, visc], dtype=np.float64).tofile(f)
             for a in (g.z, g.zh, g.dz, g.dzh, g.dzi, g.dzhi, g.dzi4, g.dzhi4, c.rhoref, c.rhorefh, c.u, c.v, c.w, c.s[0], c.ut, c.vt, c.wt, c.st[0],
-                      c.u_fluxbot, c.u_fluxtop, c.v_fluxbot, c.v_fluxtop, c.s_fluxbot, c.s_fluxtop, c.dudz, c.dvdz, c.dbdz, c.z0m, thref):
+                      c.u_fluxbot, c.u_fluxtop, c.v_fluxbot, c.v_fluxtop, c.s_fluxbot, c.s_fluxtop, c.dudz, c.dvdz, c.dbdz, c.z0m, thref) + ((threfh,) if mode & 4 else ()):
                 np.ascontiguousarray(a, dtype=np.float64).tofile(f)
         r = subprocess.run([os.path.join(CPP, "host_step"), fin, fout], capture_output=True, text=True)
         assert r.returncode == 0, r.stdout + r.stderr
@@ -59,6 +61,8 @@ def test_cpp_host_substep_matches_oracle(mode):
     ut, vt, wt, tht = c.ut.copy(), c.vt.copy(), c.wt.copy(), c.st[0].copy()
     evg = got["evisc"]          # continue from the device's evisc so that the stencil stages can be compared bit for bit
     a = (ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.rhoref), ptr(c.rhorefh))
+    if mode & 4:
+        O.orc_buoyancy_tend(G, 2, ptr(wt), ptr(c.s[0]), ptr(threfh), dbl(9.81))
     O.orc_advec_u(G, 25, ptr(ut), *a); O.orc_advec_v(G, 25, ptr(vt), *a); O.orc_advec_w(G, 25, ptr(wt), *a)
     if mode & 2:
         O.orc_advec_s_lim(G, ptr(tht), ptr(c.s[0]), *a)

@@ -191,11 +191,14 @@ def test_smag2_kernels(be, sm, dtype):
         assert same(be.host(n2), w_)
 
 
-def _oracle_rhs(c, adv, dif, sm, tPr=1./3., visc=1e-5, svisc=1e-5, limited=()):
+def _oracle_rhs(c, adv, dif, sm, tPr=1./3., visc=1e-5, svisc=1e-5, limited=(), buoy=None):
     """Advec::exec followed by Diff::exec on the oracle; returns the tendencies."""
     O = cm.oracle(); g = c.grid; Gh = g.host_struct()
     ut, vt, wt, st = c.ut.copy(), c.vt.copy(), c.wt.copy(), [x.copy() for x in c.st]
     a = (ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.rhoref), ptr(c.rhorefh))
+    if buoy is not None:          # Thermo_dry::exec runs before Advec::exec (src/model.cxx:365,388)
+        order, n, threfh, grav = buoy
+        O.orc_buoyancy_tend(Gh, order, ptr(wt), ptr(c.s[n]), ptr(threfh), dbl(grav))
     O.orc_advec_u(Gh, adv, ptr(ut), *a); O.orc_advec_v(Gh, adv, ptr(vt), *a); O.orc_advec_w(Gh, adv, ptr(wt), *a)
     for n in range(len(st)):
         if n in limited:
@@ -273,6 +276,35 @@ def test_fused_rhs_with_fluxlimit_list(be, limited, dtype):
                 assert same(a, b), (fused, "s%d" % n, limited, g.shape3, cm.ulp_diff(a, b))
         f = d.fields(); f.s_fluxlimit[0] = 1
         assert be.lib.mhh_rhs_exec(d.G, cm.ADVEC_2, cm.DIFF_2, C.byref(f), C.byref(p), be.stream) != 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("adv,dif,order", [(cm.ADVEC_2, cm.DIFF_2, 2), (cm.ADVEC_2I5, cm.DIFF_SMAG2, 2), (cm.ADVEC_4, cm.DIFF_4, 4)])
+def test_dry_buoyancy_standalone_and_folded(be, adv, dif, order, dtype):
+    """Thermo_dry buoyancy tendency (src/thermo_dry.cxx:165-197) as its own kernel and folded into the fused RHS, where it
+    is the first term added to wt like in Model::exec."""
+    O = cm.oracle(); grav = 9.81
+    for g in (grids4(dtype) if adv == cm.ADVEC_4 else grids2(dtype))[:2]:
+        c = cm.Case(g, nscalars=2); Gh = g.host_struct()
+        threfh = (300. + 0.37*np.arange(g.kcells)).astype(dtype)
+        d = B.DevCase(be, c); dth = be.arr(threfh)
+        want = c.wt.copy(); O.orc_buoyancy_tend(Gh, order, ptr(want), ptr(c.s[0]), ptr(threfh), dbl(grav))
+        t = be.arr(c.wt)
+        B.ok(be, be.lib.mhh_thermo_dry_buoyancy_tend(d.G, order, be.ptr(t), be.ptr(d.s[0]), be.ptr(dth), grav, be.stream))
+        assert same(be.host(t), want) and not np.array_equal(want, c.wt)
+        for nth in (0, 1):          # scalar 0 rides inside the march kernel, scalar 1 takes the separate kernel first
+            want = _oracle_rhs(c, adv, dif, 1 if dif == cm.DIFF_SMAG2 else 0, buoy=(order, nth, threfh, grav))
+            d = B.DevCase(be, c); f = d.fields()
+            p = capi.MhhDiffParams(); p.cs = 0.23; p.tPr = 1./3.; p.surface_model = 1 if dif == cm.DIFF_SMAG2 else 0
+            p.buoyancy = order; p.th_for_N2 = nth; p.threfh = be.ptr(dth).value; p.grav = grav
+            B.ok(be, be.lib.mhh_rhs_exec(d.G, adv, dif, C.byref(f), C.byref(p), be.stream))
+            got = (be.host(d.ut), be.host(d.vt), be.host(d.wt), [be.host(x) for x in d.st])
+            for a, b, nm in zip(got[:3], want[:3], "uvw"):
+                assert same(a, b), ("folded buoyancy", nm, adv, nth, g.shape3, cm.ulp_diff(a, b))
+            for a, b in zip(got[3], want[3]):
+                assert same(a, b)
+        p.th_for_N2 = 7
+        assert be.lib.mhh_rhs_exec(d.G, adv, dif, C.byref(f), C.byref(p), be.stream) != 0
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
