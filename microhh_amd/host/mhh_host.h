@@ -14,6 +14,7 @@
 #pragma once
 #include <array>
 #include <cmath>
+#include <cstdio>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -138,6 +139,62 @@ inline int scalar_index(const Fields<TF>& f, const std::string& name)
     for (auto& it : f.sp) { if (it.first == name) return n; ++n; }
     return -1;
 }
+
+// ---- Field3d_io (include/field3d_io.h; src/field3d_io.cxx:54-230) ---------------------------------------------------
+// Restart files in the reference's layout: the interior (kmax x jtot x itot, C order) as a raw TF stream, data + offset.
+// Host arrays; a y-slab rank (npy > 1) writes / reads its rows of the shared global file at j offset mpicoordy*jmax.
+template<typename TF>
+class Field3d_io
+{
+    public:
+        explicit Field3d_io(Grid<TF>& gridin) : grid(gridin) {}
+        // tmp1 holds imax*jmax*(kend-kstart) values; tmp2 is unused (the reference's transposed write needs it)
+        int save_field3d(const TF* data, TF* tmp1, TF*, const char* filename, TF offset, int kstart, int kend)
+        {
+            const auto& gd = grid.get_grid_data();
+            const int kmax = kend - kstart;
+            for (int k=0; k<kmax; ++k)
+                for (int j=0; j<gd.jmax; ++j)
+                    for (int i=0; i<gd.imax; ++i)
+                        tmp1[i + j*gd.imax + k*gd.imax*gd.jmax] = data[i+gd.igc + (j+gd.jgc)*gd.icells + (k+kstart)*gd.ijcells] + offset;
+            FILE* f = std::fopen(filename, (gd.npy > 1 && gd.mpicoordy > 0) ? "r+b" : "wb");
+            if (!f) return 1;
+            int nerror = 0;
+            for (int k=0; k<kmax && !nerror; ++k)
+            {
+                const long long pos = ((long long)k*gd.jtot + (long long)gd.mpicoordy*gd.jmax) * gd.itot * (long long)sizeof(TF);
+                if (std::fseek(f, pos, SEEK_SET)) { ++nerror; break; }
+                const size_t n = (size_t)gd.imax*gd.jmax;
+                if (std::fwrite(tmp1 + (size_t)k*n, sizeof(TF), n, f) != n) ++nerror;
+            }
+            if (std::fclose(f)) ++nerror;
+            return nerror;
+        }
+        int load_field3d(TF* data, TF* tmp1, TF*, const char* filename, TF offset, int kstart, int kend)
+        {
+            const auto& gd = grid.get_grid_data();
+            const int kmax = kend - kstart;
+            FILE* f = std::fopen(filename, "rb");
+            if (!f) return 1;
+            int nerror = 0;
+            for (int k=0; k<kmax && !nerror; ++k)
+            {
+                const long long pos = ((long long)k*gd.jtot + (long long)gd.mpicoordy*gd.jmax) * gd.itot * (long long)sizeof(TF);
+                if (std::fseek(f, pos, SEEK_SET)) { ++nerror; break; }
+                const size_t n = (size_t)gd.imax*gd.jmax;
+                if (std::fread(tmp1 + (size_t)k*n, sizeof(TF), n, f) != n) ++nerror;
+            }
+            std::fclose(f);
+            if (nerror) return nerror;
+            for (int k=0; k<kmax; ++k)
+                for (int j=0; j<gd.jmax; ++j)
+                    for (int i=0; i<gd.imax; ++i)
+                        data[i+gd.igc + (j+gd.jgc)*gd.icells + (k+kstart)*gd.ijcells] = tmp1[i + j*gd.imax + k*gd.imax*gd.jmax] - offset;
+            return 0;
+        }
+    private:
+        Grid<TF>& grid;
+};
 
 // ---- Boundary_cyclic (include/boundary_cyclic.h:35-70) ----------------------------------------------------------
 enum class Edge { East_west_edge, North_south_edge, Both_edges };

@@ -264,6 +264,28 @@ class HotPath:
         self._ok(self.lib.mhh_advec_cfl(self.G, self.cfg["advec"], self.u.data_ptr(), self.v.data_ptr(), self.w.data_ptr(), dt, self.work.data_ptr(), C.byref(out), self.stream))
         return self._allmax(out.value)
 
+    # -- restart files in the reference's layout (microhh_amd/fieldio.py; src/field3d_io.cxx:54-230) ------------------
+    def _restart_fields(self):
+        names = [("u", self.u), ("v", self.v), ("w", self.w)]
+        names += [("th" if n == 0 else "s%d" % n, t) for n, t in enumerate(self.s)]
+        return names
+
+    def save(self, path, iteration=0):
+        """Write the prognostic fields as `name.NNNNNNN`; slab ranks write their rows of the one global file."""
+        from . import fieldio
+        if self.rank == 0:
+            fieldio.save_grid(path, self.grid, jtot=self.grid.jmax * self.npy)
+        for name, t in self._restart_fields():
+            fieldio.save_field3d(fieldio.field_filename(path, name, iteration), t.detach().cpu().numpy(), self.grid, rank=self.rank, npy=self.npy)
+
+    def load(self, path, iteration=0):
+        """Read the prognostic fields' interiors back (ghost cells are refreshed by the next cyclic_prognostic())."""
+        from . import fieldio
+        for name, t in self._restart_fields():
+            a = fieldio.load_field3d(fieldio.field_filename(path, name, iteration), self.grid, rank=self.rank, npy=self.npy,
+                                     out=t.detach().cpu().numpy().copy())
+            t.copy_(self.torch.from_numpy(a.reshape(-1)).to(t.device).reshape(t.shape))
+
     def close(self):
         if self.plan:
             (self.lib.mhh_pres_slab_plan_destroy if self.slab else self.lib.mhh_pres_plan_destroy)(self.plan)

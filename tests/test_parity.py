@@ -11,6 +11,7 @@ Tolerances (fp64 and fp32 alike, stated per test):
   * pressure solve: |dp| <= 1e-11 max|p| fp64 / 2e-4 fp32 (rocFFT vs the oracle's DFT; complex vs half-complex solve).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -430,4 +431,27 @@ def test_slab_code_path_on_one_rank(be, dtype):
     for n in ("p", "ut", "vt", "wt"):
         x, y = be.host(getattr(a, n))[it], be.host(getattr(b, n))[it]
         assert np.abs(x - y).max() <= tol * np.abs(x).max(), (n, np.abs(x - y).max() / np.abs(x).max())
+    a.close(); b.close()
+
+
+def test_hotpath_restart_files_roundtrip(be, tmp_path):
+    """HotPath.save / load: prognostic fields through the reference's field-file layout and back, bit for bit."""
+    from microhh_amd.model import HotPath, synthetic_global
+    shape = (16, 12, 10)
+    dev = "cuda:0" if be.name == "hip" else "cpu"
+    gi = synthetic_global("drycblles", *shape)
+    a = HotPath("drycblles", *shape, device=dev, lib=be.lib, global_init=gi)
+    b = HotPath("drycblles", *shape, device=dev, lib=be.lib, seed=99)
+    a.save(str(tmp_path), 42)
+    assert sorted(os.listdir(str(tmp_path))) == ["grid.0000000", "th.0000042", "u.0000042", "v.0000042", "w.0000042"]
+    assert os.path.getsize(str(tmp_path / "u.0000042")) == 8 * 16 * 12 * 10
+    b.load(str(tmp_path), 42)
+    it = a.grid.interior
+    for n in ("u", "v", "w"):
+        assert np.array_equal(be.host(getattr(a, n))[it], be.host(getattr(b, n))[it]), n
+    assert np.array_equal(be.host(a.s[0])[it], be.host(b.s[0])[it])
+    for hp in (a, b):
+        hp.cyclic_prognostic()
+    for n in ("u", "v", "w"):                     # lateral ghost cells refilled from the loaded interiors
+        assert np.array_equal(be.host(getattr(a, n))[it[0]], be.host(getattr(b, n))[it[0]]), n
     a.close(); b.close()
