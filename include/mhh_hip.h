@@ -194,6 +194,11 @@ typedef struct mhh_diff_params
      * src/model.cxx:365,388): wt += grav/threfh[k]*(th_h - threfh[k]) for scalar th_for_N2, first. */
     int    buoyancy;         /* 0 = off, 2 / 4 = interpolation order (swspatialorder)      */
     const void* threfh;      /* [kcells]                                                   */
+    /* slab decomposition (npy > 1): also evaluate evisc on the ghost rows jstart-1 and jend from the
+     * u, v, w (, th) halos instead of exchanging it -- the same operands as on the neighbour, hence
+     * the same bits; the diffusion kernels read evisc one row beyond the slab only. Needs jgc >= 2 and
+     * the 2-D surface inputs valid on those rows.                                                      */
+    int    evisc_ghost_rows;
 } mhh_diff_params;
 int mhh_diff_exec_viscosity(const mhh_grid* g, int scheme, const mhh_fields* f, const mhh_diff_params* p, void* stream);
 int mhh_diff_exec(const mhh_grid* g, int scheme, const mhh_fields* f, const mhh_diff_params* p, void* stream);
@@ -247,6 +252,14 @@ int mhh_pres_output_order(const mhh_grid* g, int order, const mhh_fields* f, voi
 unsigned long long mhh_halo_buffer_elems(const mhh_grid* g, int nfields);
 int mhh_halo_pack_ns  (const mhh_grid* g, void* const* fields, int nfields, void* send_south, void* send_north, void* stream);
 int mhh_halo_unpack_ns(const mhh_grid* g, void* const* fields, int nfields, const void* recv_from_south, const void* recv_from_north, void* stream);
+/* partial exchange: rows_south rows travel south, rows_north rows travel north (0..jgc each), buffers
+ * [field][k][rows][icells]. pres_2 input reads vt[j+1] only (src/pres_2.cxx:181,193): rows_south = 1, rows_north = 0;
+ * pres_2 output reads p[j-1] only (:383-385): rows_south = 0, rows_north = 1. On unpack, recv_from_south holds the
+ * rows_north rows the south neighbour sent north, recv_from_north the rows_south rows the north neighbour sent south. */
+int mhh_halo_pack_rows  (const mhh_grid* g, void* const* fields, int nfields, int rows_south, int rows_north,
+                         void* send_south, void* send_north, void* stream);
+int mhh_halo_unpack_rows(const mhh_grid* g, void* const* fields, int nfields, int rows_south, int rows_north,
+                         const void* recv_from_south, const void* recv_from_north, void* stream);
 /* pres_2 split at the transposes. All-to-all buffers hold mhh_pres_slab_xbuf_elems() COMPLEX elements,
  * laid out [peer][k][jl][kxl] so that one equal-split all_to_all moves them.                               */
 typedef struct mhh_pres_slab_plan mhh_pres_slab_plan;

@@ -30,7 +30,7 @@ class MhhFields(C.Structure):
 class MhhDiffParams(C.Structure):
     _fields_ = [("cs", cd), ("tPr", cd), ("surface_model", ci), ("neutral", ci), ("N2", vp),
                 ("th_for_N2", ci), ("thref", vp), ("grav", cd), ("mlen0", vp),
-                ("buoyancy", ci), ("threfh", vp)]
+                ("buoyancy", ci), ("threfh", vp), ("evisc_ghost_rows", ci)]
 
 
 FP = C.POINTER(MhhFields)
@@ -82,6 +82,8 @@ SIGNATURES = {
     "mhh_halo_buffer_elems": (C.c_ulonglong, [GP, ci]),
     "mhh_halo_pack_ns": (ci, [GP, C.POINTER(vp), ci, vp, vp, vp]),
     "mhh_halo_unpack_ns": (ci, [GP, C.POINTER(vp), ci, vp, vp, vp]),
+    "mhh_halo_pack_rows": (ci, [GP, C.POINTER(vp), ci, ci, ci, vp, vp, vp]),
+    "mhh_halo_unpack_rows": (ci, [GP, C.POINTER(vp), ci, ci, ci, vp, vp, vp]),
     "mhh_pres_slab_plan_create": (ci, [GP, vp, vp, vp, vp, C.POINTER(PLAN)]),
     "mhh_pres_slab_plan_destroy": (None, [PLAN]),
     "mhh_pres_slab_xbuf_elems": (C.c_ulonglong, [PLAN]),

@@ -164,10 +164,14 @@ MHH_API int mhh_diff_exec_viscosity(const mhh_grid* g, int scheme, const mhh_fie
         }
     }
     MHH_REQUIRE(!(p->neutral && !p->surface_model), "neutral + resolved walls: use mhh_smag2_strain2 + mhh_smag2_evisc_neutral");
+    MHH_REQUIRE(!p->evisc_ghost_rows || g->jgc >= 2, "evisc_ghost_rows needs jgc >= 2");
     hipStream_t st = as_stream(stream);
 #define CALL(TF) [&]{ ViscosityOp<TF> op{make_grid<TF>(g), p->surface_model, p->neutral, mp<TF>(f->evisc), cp<TF>(f->u), cp<TF>(f->v), cp<TF>(f->w), \
                           cp<TF>(f->dudz), cp<TF>(f->dvdz), cp<TF>(f->dbdz), cp<TF>(f->z0m), cp<TF>(p->N2), cp<TF>(th), cp<TF>(p->thref), TF(p->grav), cp<TF>(p->mlen0), TF(p->tPr)}; \
                       if (int e = launch_interior(st, op.g, g->kstart, g->kend, op)) return e; \
+                      if (p->evisc_ghost_rows) { \
+                          if (int e = launch_cells(st, op, g->istart, g->iend, g->jstart-1, g->jstart, g->kstart, g->kend, g->icells, g->ijcells)) return e; \
+                          if (int e = launch_cells(st, op, g->istart, g->iend, g->jend, g->jend+1, g->kstart, g->kend, g->icells, g->ijcells)) return e; } \
                       if (!p->surface_model) { MirrorWallOp2<TF> m{op.g, mp<TF>(f->evisc)}; if (int e = launch_cells(st, m, 0, g->icells, 0, g->jcells, 0, 1, g->icells, g->ijcells)) return e; } \
                       return MHH_OK; }()
     if (int e = MHH_DISPATCH(g, CALL)) return e;

@@ -22,36 +22,38 @@ using namespace mhh;
 constexpr int MAXF = 8;
 template<class TF> struct FieldList { TF* f[MAXF]; };
 
+// rs rows travel south (my southernmost interior rows -> the first rs north ghost rows of the south neighbour), rn rows
+// travel north (my northernmost interior rows -> the rn south ghost rows next to the north neighbour's interior).
+// The full exchange is rs = rn = jgc; a consumer that reads one row beyond the slab in one direction only (pres input:
+// vt[j+1]; pres output: p[j-1]) moves just that row.
 template<class TF, bool PACK>
 __global__ void __launch_bounds__(256) halo_ns_kernel(FieldList<TF> fl, TF* __restrict__ south, TF* __restrict__ north,
-                                                      int icells, int ijcells, int kcells, int jgc, int jstart, int jend)
+                                                      int icells, int ijcells, int kcells, int jgc, int jstart, int jend, int rs, int rn)
 {
     const int i = blockIdx.x*256 + threadIdx.x;
     const int k = blockIdx.y, n = blockIdx.z;
     if (i >= icells) return;
     TF* __restrict__ a = fl.f[n] + (size_t)k*ijcells;
-    const size_t b = ((size_t)n*kcells + k) * jgc * icells + i;
-    for (int j=0; j<jgc; ++j)
+    const size_t bs = ((size_t)n*kcells + k) * rs * icells + i, bn = ((size_t)n*kcells + k) * rn * icells + i;
+    if (PACK)
     {
-        if (PACK)
-        {
-            south[b + (size_t)j*icells] = a[i + (jstart + j)*icells];        // my southernmost interior rows -> south neighbour's north ghosts
-            north[b + (size_t)j*icells] = a[i + (jend - jgc + j)*icells];    // my northernmost interior rows -> north neighbour's south ghosts
-        }
-        else
-        {
-            a[i + j*icells] = south[b + (size_t)j*icells];                   // south ghosts <- what the south neighbour sent north
-            a[i + (jend + j)*icells] = north[b + (size_t)j*icells];          // north ghosts <- what the north neighbour sent south
-        }
+        for (int j=0; j<rs; ++j) south[bs + (size_t)j*icells] = a[i + (jstart + j)*icells];
+        for (int j=0; j<rn; ++j) north[bn + (size_t)j*icells] = a[i + (jend - rn + j)*icells];
+    }
+    else
+    {
+        // `south` holds what the south neighbour sent north (its rn rows), `north` what the north neighbour sent south (rs rows)
+        for (int j=0; j<rn; ++j) a[i + (jgc - rn + j)*icells] = south[bn + (size_t)j*icells];
+        for (int j=0; j<rs; ++j) a[i + (jend + j)*icells] = north[bs + (size_t)j*icells];
     }
 }
 template<class TF, bool PACK>
-static int halo_launch(const mhh_grid* g, void* const* fields, int nf, void* south, void* north, hipStream_t st)
+static int halo_launch(const mhh_grid* g, void* const* fields, int nf, void* south, void* north, int rs, int rn, hipStream_t st)
 {
     FieldList<TF> fl;
     for (int n=0; n<MAXF; ++n) fl.f[n] = mp<TF>(fields[n < nf ? n : 0]);
     hipLaunchKernelGGL((halo_ns_kernel<TF, PACK>), dim3((g->icells + 255)/256, g->kcells, nf), dim3(256), 0, st, fl, mp<TF>(south), mp<TF>(north),
-                       g->icells, g->ijcells, g->kcells, g->jgc, g->jstart, g->jend);
+                       g->icells, g->ijcells, g->kcells, g->jgc, g->jstart, g->jend, rs, rn);
     MHH_LAUNCH_CHECK();
     return MHH_OK;
 }
@@ -63,18 +65,24 @@ static int halo_check(const mhh_grid* g, void* const* fields, int nf, const void
     MHH_REQUIRE(g->jmax >= g->jgc, "jmax >= jgc (src/grid.cxx:420)");
     return MHH_OK;
 }
-MHH_API int mhh_halo_pack_ns(const mhh_grid* g, void* const* fields, int nf, void* send_south, void* send_north, void* stream)
+MHH_API int mhh_halo_pack_rows(const mhh_grid* g, void* const* fields, int nf, int rows_south, int rows_north, void* send_south, void* send_north, void* stream)
 {
     if (int e = halo_check(g, fields, nf, send_south, send_north)) return e;
-    if (g->dtype == MHH_F64) return halo_launch<double, true>(g, fields, nf, send_south, send_north, as_stream(stream));
-    return halo_launch<float, true>(g, fields, nf, send_south, send_north, as_stream(stream));
+    MHH_REQUIRE(rows_south >= 0 && rows_south <= g->jgc && rows_north >= 0 && rows_north <= g->jgc && rows_south + rows_north > 0, "0 <= rows <= jgc");
+    if (g->dtype == MHH_F64) return halo_launch<double, true>(g, fields, nf, send_south, send_north, rows_south, rows_north, as_stream(stream));
+    return halo_launch<float, true>(g, fields, nf, send_south, send_north, rows_south, rows_north, as_stream(stream));
 }
-MHH_API int mhh_halo_unpack_ns(const mhh_grid* g, void* const* fields, int nf, const void* recv_south, const void* recv_north, void* stream)
+MHH_API int mhh_halo_unpack_rows(const mhh_grid* g, void* const* fields, int nf, int rows_south, int rows_north, const void* recv_south, const void* recv_north, void* stream)
 {
     if (int e = halo_check(g, fields, nf, recv_south, recv_north)) return e;
-    if (g->dtype == MHH_F64) return halo_launch<double, false>(g, fields, nf, const_cast<void*>(recv_south), const_cast<void*>(recv_north), as_stream(stream));
-    return halo_launch<float, false>(g, fields, nf, const_cast<void*>(recv_south), const_cast<void*>(recv_north), as_stream(stream));
+    MHH_REQUIRE(rows_south >= 0 && rows_south <= g->jgc && rows_north >= 0 && rows_north <= g->jgc && rows_south + rows_north > 0, "0 <= rows <= jgc");
+    if (g->dtype == MHH_F64) return halo_launch<double, false>(g, fields, nf, const_cast<void*>(recv_south), const_cast<void*>(recv_north), rows_south, rows_north, as_stream(stream));
+    return halo_launch<float, false>(g, fields, nf, const_cast<void*>(recv_south), const_cast<void*>(recv_north), rows_south, rows_north, as_stream(stream));
 }
+MHH_API int mhh_halo_pack_ns(const mhh_grid* g, void* const* fields, int nf, void* send_south, void* send_north, void* stream)
+{ return mhh_halo_pack_rows(g, fields, nf, g ? g->jgc : 0, g ? g->jgc : 0, send_south, send_north, stream); }
+MHH_API int mhh_halo_unpack_ns(const mhh_grid* g, void* const* fields, int nf, const void* recv_south, const void* recv_north, void* stream)
+{ return mhh_halo_unpack_rows(g, fields, nf, g ? g->jgc : 0, g ? g->jgc : 0, recv_south, recv_north, stream); }
 MHH_API unsigned long long mhh_halo_buffer_elems(const mhh_grid* g, int nf)
 {
     return (unsigned long long)nf * g->kcells * g->jgc * g->icells;

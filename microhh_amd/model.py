@@ -53,7 +53,7 @@ class HotPath:
     """Device-resident fields of ONE rank + the operator calls of one sub-step."""
 
     def __init__(self, case, itot, jtot, ktot, dtype=np.float64, device="cuda:0", seed=666, dt=1.0,
-                 lib=None, npy=1, rank=0, group=None, global_init=None, force_slab=False):
+                 lib=None, npy=1, rank=0, group=None, global_init=None, force_slab=False, slim_halos=True):
         import torch
         self.torch = torch
         self.lib = lib if lib is not None else capi.lib()
@@ -62,6 +62,9 @@ class HotPath:
         # slab code path (halo pack/unpack, split pressure solve); force_slab runs it on ONE rank with the exchanges
         # degenerated to local copies, which is how the slab kernels are exercised on a single-GPU box
         self.slab = (npy > 1) or force_slab
+        # slim_halos: exchange only what the next kernel reads across the slab edge (one row of vt and of p, one direction
+        # each) and evaluate evisc on the two adjacent ghost rows locally instead of exchanging it
+        self.slim = bool(slim_halos)
         self.device = torch.device(device)
         self.on_gpu = self.device.type == "cuda"
         if self.slab and cfg["pres"] != 2:
@@ -135,6 +138,11 @@ class HotPath:
             self.xrecv = torch.zeros(2*nx, device=self.device, dtype=td)
             self._halo = {}
         self._prog = [self.u, self.v, self.w] + self.s
+        self.evisc_local_ghosts = self.slab and self.slim and cfg["diff"] == DIFF_SMAG2 and g.jgc >= 2
+        if self.evisc_local_ghosts:
+            p.evisc_ghost_rows = 1
+            for k in ("dudz", "dvdz", "dbdz", "z0m"):
+                self._halo2d(self.surf[k])
         self.cyclic_prognostic()
         self.sync()
 
@@ -170,32 +178,58 @@ class HotPath:
         return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
     # -- halos ------------------------------------------------------------------------------------------------
-    def halo(self, tensors):
+    def halo(self, tensors, rows_south=None, rows_north=None):
         """Periodic ghost cells of 3-D fields: east-west wrap on the device, north-south wrap locally (npy == 1) or
-        by exchanging jgc rows with the ring neighbours (Boundary_cyclic::exec, src/boundary_cyclic.cxx:116-176)."""
+        by exchanging rows with the ring neighbours (Boundary_cyclic::exec, src/boundary_cyclic.cxx:116-176).
+        rows_south / rows_north: how many of my southernmost / northernmost interior rows travel to the south / north
+        neighbour (default jgc each = the reference's full exchange)."""
         arr = self._ptrs(tensors)
         if not self.slab:
             self._ok(self.lib.mhh_boundary_cyclic_n(self.G, arr, len(tensors), EDGE_BOTH, self.stream))
             return
         import torch.distributed as dist
         self._ok(self.lib.mhh_boundary_cyclic_n(self.G, arr, len(tensors), EDGE_EW, self.stream))
-        nf = len(tensors)
-        if nf not in self._halo:
-            n = int(self.lib.mhh_halo_buffer_elems(self.G, nf))
-            self._halo[nf] = [self.torch.zeros(n, device=self.device, dtype=self.td) for _ in range(4)]
-        s_south, s_north, r_south, r_north = self._halo[nf]
-        self._ok(self.lib.mhh_halo_pack_ns(self.G, arr, nf, s_south.data_ptr(), s_north.data_ptr(), self.stream))
+        g, nf = self.grid, len(tensors)
+        rs = g.jgc if rows_south is None else rows_south
+        rn = g.jgc if rows_north is None else rows_north
+        key = (nf, rs, rn)
+        if key not in self._halo:
+            per_row = nf * g.kcells * g.icells
+            mk = lambda rows: self.torch.zeros(max(1, rows * per_row), device=self.device, dtype=self.td)
+            self._halo[key] = [mk(rs), mk(rn), mk(rn), mk(rs)]      # send south, send north, recv from south, recv from north
+        s_south, s_north, r_south, r_north = self._halo[key]
+        self._ok(self.lib.mhh_halo_pack_rows(self.G, arr, nf, rs, rn, s_south.data_ptr(), s_north.data_ptr(), self.stream))
         if self.npy == 1:          # both neighbours are this rank: the exchange is a local swap
             r_south.copy_(s_north); r_north.copy_(s_south)
-            self._ok(self.lib.mhh_halo_unpack_ns(self.G, arr, nf, r_south.data_ptr(), r_north.data_ptr(), self.stream))
+        else:
+            south, north = (self.rank - 1) % self.npy, (self.rank + 1) % self.npy
+            ranks = dist.get_process_group_ranks(self.group) if self.group is not None else list(range(self.npy))
+            ops = []
+            if rn: ops.append(dist.P2POp(dist.isend, s_north, ranks[north], self.group))
+            if rs: ops.append(dist.P2POp(dist.isend, s_south, ranks[south], self.group))
+            if rn: ops.append(dist.P2POp(dist.irecv, r_south, ranks[south], self.group))
+            if rs: ops.append(dist.P2POp(dist.irecv, r_north, ranks[north], self.group))
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        self._ok(self.lib.mhh_halo_unpack_rows(self.G, arr, nf, rs, rn, r_south.data_ptr(), r_north.data_ptr(), self.stream))
+
+    def _halo2d(self, t):
+        """One-time periodic ghost cells of a 2-D surface array (Boundary_cyclic::exec_2d, src/boundary_cyclic.cxx:445-500)."""
+        g = self.grid
+        if self.npy == 1:
+            self._ok(self.lib.mhh_boundary_cyclic_2d(self.G, t.data_ptr(), self.stream))
             return
+        import torch.distributed as dist
+        t[:, :g.igc] = t[:, g.iend-g.igc:g.iend].clone(); t[:, g.iend:] = t[:, g.istart:g.istart+g.igc].clone()
+        s_north, s_south = t[g.jend-g.jgc:g.jend].contiguous(), t[g.jstart:g.jstart+g.jgc].contiguous()
+        r_south, r_north = self.torch.empty_like(s_north), self.torch.empty_like(s_south)
         south, north = (self.rank - 1) % self.npy, (self.rank + 1) % self.npy
         ranks = dist.get_process_group_ranks(self.group) if self.group is not None else list(range(self.npy))
         ops = [dist.P2POp(dist.isend, s_north, ranks[north], self.group), dist.P2POp(dist.isend, s_south, ranks[south], self.group),
                dist.P2POp(dist.irecv, r_south, ranks[south], self.group), dist.P2POp(dist.irecv, r_north, ranks[north], self.group)]
         for w in dist.batch_isend_irecv(ops):
             w.wait()
-        self._ok(self.lib.mhh_halo_unpack_ns(self.G, arr, nf, r_south.data_ptr(), r_north.data_ptr(), self.stream))
+        t[:g.jgc] = r_south; t[g.jend:] = r_north
 
     def cyclic_prognostic(self):
         self.halo(self._prog)
@@ -203,7 +237,7 @@ class HotPath:
     # -- the operator calls -----------------------------------------------------------------------------------
     def exec_viscosity(self):
         self._ok(self.lib.mhh_diff_exec_viscosity(self.G, self.cfg["diff"], C.byref(self.fields), C.byref(self.params), self.stream))
-        if self.slab and self.cfg["diff"] == DIFF_SMAG2:
+        if self.slab and self.cfg["diff"] == DIFF_SMAG2 and not self.evisc_local_ghosts:
             self.halo([self.evisc])
 
     def rhs(self):
@@ -219,7 +253,8 @@ class HotPath:
             return
         import torch.distributed as dist
         lib, st = self.lib, self.stream
-        self.halo([self.vt])                                        # vt[j+1] at the slab edge (pres_2.cxx:181)
+        if self.slim: self.halo([self.vt], rows_south=1, rows_north=0)      # only vt[j+1] at the north edge is read (pres_2.cxx:181,193)
+        else:         self.halo([self.vt])
         packed = lib.mhh_pres_slab_packed(self.plan)
         self._ok(lib.mhh_pres_input_packed(self.G, 2, C.byref(self.fields), self.dt, packed, st))
         self._ok(lib.mhh_pres_fwd_x_pack(self.plan, self.G, packed, self.xsend.data_ptr(), st))
@@ -227,7 +262,8 @@ class HotPath:
         self._ok(lib.mhh_pres_fwd_y_solve_bwd_y(self.plan, self.G, self.xrecv.data_ptr(), self.xsend.data_ptr(), self.stream))
         self._transpose()                                                    # Transpose::exec_yx
         self._ok(lib.mhh_pres_bwd_x_unpack(self.plan, self.G, self.xrecv.data_ptr(), C.byref(self.fields), self.stream))
-        self.halo([self.p])
+        if self.slim: self.halo([self.p], rows_south=0, rows_north=1)       # only p[j-1] at the south edge is read (pres_2.cxx:383-385)
+        else:         self.halo([self.p])
         self._ok(lib.mhh_pres_output_order(self.G, 2, C.byref(self.fields), self.stream))
 
     def _transpose(self):

@@ -40,12 +40,14 @@ def _run(hp, out):
     out["cfl"] = np.array(hp.cfl(0.5))
 
 
-def _worker(rank, world, port, tmp):
+def _worker(rank, world, port, tmp, slim):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         lib = B.get("emul").lib
-        hp = HotPath("drycblles", *GRID, device="cpu", lib=lib, npy=world, rank=rank, global_init=synthetic_global("drycblles", *GRID))
+        hp = HotPath("drycblles", *GRID, device="cpu", lib=lib, npy=world, rank=rank, global_init=synthetic_global("drycblles", *GRID),
+                     slim_halos=slim)
+        assert hp.evisc_local_ghosts == slim
         out = {}
         _run(hp, out)
         np.savez(os.path.join(tmp, "rank%d.npz" % rank), **out)
@@ -54,15 +56,17 @@ def _worker(rank, world, port, tmp):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_slab_matches_single_rank(world):
+@pytest.mark.parametrize("world,slim", [(2, True), (4, True), (2, False)], ids=["2-slim", "4-slim", "2-full-halos"])
+def test_slab_matches_single_rank(world, slim):
+    """slim: one-row vt / p exchanges and evisc evaluated on the adjacent ghost rows; full: the reference's jgc-row
+    exchanges of vt, p and evisc. Both must reproduce the single-rank bits."""
     lib = B.get("emul").lib
     ref = {}
     hp = HotPath("drycblles", *GRID, device="cpu", lib=lib, global_init=synthetic_global("drycblles", *GRID))
     _run(hp, ref)
     hp.close()
     with tempfile.TemporaryDirectory() as tmp:
-        mp.spawn(_worker, args=(world, 29500 + world + os.getpid() % 1000, tmp), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, 29500 + world + 7*int(slim) + os.getpid() % 1000, tmp, slim), nprocs=world, join=True)
         parts = [np.load(os.path.join(tmp, "rank%d.npz" % r)) for r in range(world)]
         for key in ("evisc", "rhs_ut", "rhs_vt", "rhs_wt", "rhs_st"):
             got = np.concatenate([p[key] for p in parts], axis=1)
