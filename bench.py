@@ -29,7 +29,11 @@ WORKLOADS = {
     "moser600": ("moser600", 512, 256, 256, "moser600 512x256x256 fp64, advec_4 + diff_4 + pres_4 (BASELINE.json configs[2])"),
     "slab8of512": ("drycblles", 512, 64, 512, "one rank's share (512x64x512) of drycblles 512^3 on 8 GPUs, run alone: per-rank compute estimate"),
     "taylorgreen64": ("taylorgreen", 64, 64, 64, "taylorgreen 64^3 fp64, advec_2 + diff_2 + pres_2 (BASELINE.json configs[0])"),
+    # BASELINE.json configs[4]: fp32, RHS only (exec_viscosity + advec_2i5 + diff_smag2; no pressure solve in that config)
+    "gabls1_1024": ("gabls1", 1024, 1024, 256, "gabls1 1024x1024x256 fp32, advec_2i5 + diff_smag2, RHS only (BASELINE.json configs[4] grid on N GPUs)"),
+    "gabls1_slab8": ("gabls1", 1024, 128, 256, "one rank's share (1024x128x256) of gabls1 1024x1024x256 fp32 on 8 GPUs, run alone, RHS only"),
 }
+FP32_RHS_ONLY = ("gabls1_1024", "gabls1_slab8")
 
 
 def cpu_baseline(case, sample=(128, 128, 128), reps=3):
@@ -103,8 +107,9 @@ def main():
 
     case, itot, jtot, ktot, desc = WORKLOADS[args.workload]
     from microhh_amd.model import HotPath
+    rhs_only = args.workload in FP32_RHS_ONLY
     hp = HotPath(case, itot, jtot, ktot, device="cuda:%d" % local, npy=world, rank=rank,   # slab in y: npx=1, npy=world
-                 force_slab=(args.force_slab and world == 1))
+                 force_slab=(args.force_slab and world == 1), dtype=(np.float32 if rhs_only else np.float64))
 
     rhs = hp.rhs_unfused if args.unfused else hp.rhs
 
@@ -116,7 +121,8 @@ def main():
         rhs()
         if ev is not None:
             ev[1].record()
-        hp.pres()
+        if not rhs_only:
+            hp.pres()
 
     for _ in range(args.warmup):
         one_step()
@@ -144,19 +150,24 @@ def main():
     alg_bytes = hp.alg_bytes_rhs() * local_cells
     achieved = alg_bytes / (rhs_ms * 1e-3) / 1e9
     out = {
-        "metric": "grid-cell updates/sec (full RHS+pres step)", "value": cells / (elapsed / args.steps), "unit": "grid-cell updates/s",
+        "metric": "grid-cell updates/sec (full RHS+pres step)" if not rhs_only else "grid-cell updates/sec (RHS: exec_viscosity + advec + diff)", "value": cells / (elapsed / args.steps), "unit": "grid-cell updates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32" if rhs_only else "f64", "data": "synthetic",
         "config": {"workload": desc, "grid": [itot, jtot, ktot], "decomposition": "slab-y npx=1 npy=%d" % world,
                    "rhs": "unfused" if args.unfused else "fused"},
         "roofline": {"bound": "hbm", "kernel": "fused RHS (advec+diff) pass" if not args.unfused else "advec+diff launches",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None, "alg_bytes_per_cell": hp.alg_bytes_rhs(), "ms_per_launch": rhs_ms},
-        "alg_bytes_per_cell_full_step": hp.alg_bytes_rhs() + hp.alg_bytes_visc() + hp.alg_bytes_pres(),
-        "hbm_frac_full_step": (hp.alg_bytes_rhs() + hp.alg_bytes_visc() + hp.alg_bytes_pres()) * local_cells / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "alg_bytes_per_cell_full_step": hp.alg_bytes_rhs() + hp.alg_bytes_visc() + (0 if rhs_only else hp.alg_bytes_pres()),
+        "hbm_frac_full_step": (hp.alg_bytes_rhs() + hp.alg_bytes_visc() + (0 if rhs_only else hp.alg_bytes_pres())) * local_cells / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
     }
+    if args.workload == "drycblles512" and world == 1 and not args.unfused:
+        # HBM bytes per launch of this kernel on this workload from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and
+        # WRITE_SIZE in separate runs, FETCH_SIZE doubled for gfx950): profiles/r1c_march_kernel_pmc.md
+        out["roofline"]["traffic"] = (7.26e6 * 2 + 4.26e6) * 1024
+        out["roofline"]["traffic_source"] = "profiles/r1c_march_kernel_pmc.md"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(case)
+        out["cpu_baseline"] = cpu_baseline("drycblles" if case == "gabls1" else case)
     hp.close()
     if rank == 0:
         print(json.dumps(out), flush=True)

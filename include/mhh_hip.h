@@ -201,6 +201,9 @@ typedef struct mhh_diff_params
     int    evisc_ghost_rows;
 } mhh_diff_params;
 int mhh_diff_exec_viscosity(const mhh_grid* g, int scheme, const mhh_fields* f, const mhh_diff_params* p, void* stream);
+/* diagnostic: launches of the k-marching form of exec_viscosity so far (it needs 16-byte aligned rows; other layouts
+ * take the one-thread-per-cell kernel, same bits) */
+unsigned long long mhh_stat_visc_march_launches(void);
 int mhh_diff_exec(const mhh_grid* g, int scheme, const mhh_fields* f, const mhh_diff_params* p, void* stream);
 
 /* Thermo_dry::exec buoyancy tendency, calc_buoyancy_tend_2nd / _4th (src/thermo_dry.cxx:165-197,

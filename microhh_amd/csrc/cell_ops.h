@@ -366,6 +366,23 @@ MHH_HD TF smag_strain2(const TF* __restrict__ u, const TF* __restrict__ v, const
     return s2;
 }
 
+// evisc from strain^2 (calc_evisc / calc_evisc_neutral, src/diff_smag2.cxx:157-367, the surface-model branches and the
+// plain Smagorinsky length for resolved walls): pow(x, 2) and pow(y, 1/2) are evaluated as x*x and sqrt(y).
+MHH_HD double dsqrt2(double x) { return __builtin_sqrt(x); }
+MHH_HD float  dsqrt2(float x)  { return __builtin_sqrtf(x); }
+template<class TF>
+MHH_HD TF evisc_value(TF s2, TF n2, int sm, int neutral, TF mlen0_k, TF z_k, TF z0m_ij, TF tPr)
+{
+    TF fac;
+    if (!sm) fac = sq(mlen0_k);
+    else if (neutral) fac = sq(TF(1.)/(TF(1.)/mlen0_k + TF(1.)/(TF(0.4)*(z_k+z0m_ij))));
+    else fac = sq(dsqrt2(TF(1.)/(TF(1.)/sq(mlen0_k) + TF(1.)/sq(TF(0.4)*(z_k+z0m_ij)))));
+    if (neutral) return fac * dsqrt2(s2);
+    TF rit = n2 / s2 / tPr;
+    rit = tmin(rit, TF(1.-1.e-9));
+    return fac * dsqrt2(s2) * dsqrt2(TF(1.)-rit);
+}
+
 // diff_u / diff_v (:369-571). fb/ft: this level takes the surface flux at the bottom / top instead of the resolved gradient.
 template<class TF>
 MHH_HD TF smag_diff_u(const TF* __restrict__ u, const TF* __restrict__ v, const TF* __restrict__ w, const TF* __restrict__ ev,

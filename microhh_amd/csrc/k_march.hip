@@ -16,6 +16,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include "k_common.h"
+#include "k_march_common.h"
 #include <gfx950_prims.h>   // angle form: the CPU emulation build (tests/emul) overrides it by include path
 
 using namespace mhh;
@@ -73,27 +74,6 @@ template<class TF> struct MarchFields
     TF visc, svisc, tPr; int sm;
     const TF* __restrict__ threfh; TF grav;      // folded dry buoyancy of the scalar (threfh == nullptr: off)
 };
-
-struct MarchTiling { int nbx, nby, nkc, sr, ns, kc; };
-
-__device__ __forceinline__ bool decode_march(const MarchTiling& t, unsigned L, int& bx, int& by, int& kc)
-{
-    // XCD-aware order as decode_tile (k_common.h): a unit = one strip of tiles over one k-chunk; units are dealt to the
-    // XCDs round-robin, so the tiles that share halos run next to each other on one L2.
-    const int xcd = L & 7u;
-    const unsigned tt = L >> 3;
-    const unsigned per_unit = (unsigned)t.sr * t.nbx;
-    const unsigned round = tt / per_unit;
-    unsigned r = tt - round * per_unit;
-    const int unit = (int)round * 8 + xcd;
-    if (unit >= t.ns * t.nkc) return false;
-    const int strip = unit % t.ns;
-    kc = unit / t.ns;
-    const int byl = (int)(r / t.nbx);
-    bx = (int)(r - (unsigned)byl * t.nbx);
-    by = strip * t.sr + byl;
-    return by < t.nby;
-}
 
 #ifndef MHH_MARCH_OCC
 #define MHH_MARCH_OCC 2
@@ -467,18 +447,11 @@ int march_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* 
     mf.visc = TF(f->visc); mf.svisc = has_s ? TF(f->svisc[0]) : TF(0); mf.tPr = TF(p->tPr); mf.sm = p->surface_model;
     const bool buoy = has_s && p->buoyancy == 2 && p->th_for_N2 == 0;
     mf.threfh = buoy ? cp<TF>(p->threfh) : nullptr; mf.grav = buoy ? TF(p->grav) : TF(0);
-    MarchTiling t;
-    t.nbx = (g->imax + 63)/64; t.nby = (g->jmax + NJ-1)/NJ;
 #ifndef MHH_MARCH_KC
 #define MHH_MARCH_KC 128
 #endif
-    t.kc = MHH_MARCH_KC; t.nkc = (g->kmax + t.kc - 1)/t.kc;
-    t.sr = (MHH_STRIP_ROWS + NJ-1)/NJ;
-    if (t.sr * 8 > t.nby * t.nkc) t.sr = (t.nby * t.nkc) / 8;     // enough (strip, chunk) units to occupy all 8 XCDs
-    if (t.sr < 1) t.sr = 1;
-    t.ns = (t.nby + t.sr-1)/t.sr;
-    const int units = t.ns * t.nkc;
-    const unsigned nblocks = 8u * (unsigned)((units + 7)/8) * (unsigned)t.sr * t.nbx;
+    const MarchTiling t = make_march_tiling(g, NJ, MHH_MARCH_KC);
+    const unsigned nblocks = march_blocks(t);
     // LDS-DMA needs 16-byte aligned plane rows; otherwise the register-staged variant runs (same arithmetic)
     constexpr int VEC = 16 / (int)sizeof(TF);
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };

@@ -7,6 +7,7 @@
 using namespace mhh;
 
 int mhh_rhs25_march(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, void* stream);   // k_march.hip
+int mhh_visc_march(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, const void* th, void* stream);   // k_visc.hip
 
 // =======================================================================================================
 // Max reductions (calc_cfl / calc_dnmul / calc_divergence + Master::max). All integrands are |.| >= 0, so the
@@ -103,9 +104,6 @@ MHH_API int mhh_pres_check_divergence(const mhh_grid* g, int order, const mhh_fi
 // as ONE stencil pass (the reference stores strain^2 into evisc, reads N2 from a tmp field and rewrites evisc;
 // values are identical because every intermediate is rounded to TF exactly where the reference stores it).
 // =======================================================================================================
-template<class TF> __device__ __forceinline__ TF dsqrt2(TF x);
-template<> __device__ __forceinline__ double dsqrt2<double>(double x) { return __builtin_sqrt(x); }
-template<> __device__ __forceinline__ float  dsqrt2<float>(float x)   { return __builtin_sqrtf(x); }
 
 template<class TF>
 struct ViscosityOp
@@ -121,18 +119,14 @@ struct ViscosityOp
         const bool mo = sm && (k == g.kstart);
         const TF s2 = smag_strain2(u, v, w, c, g.icells, g.ijcells, mo, mo ? dudz[ij] : TF(0), mo ? dvdz[ij] : TF(0),
                                    g.dxi_d, g.dyi_d, g.dzi[k], g.dzhi[k], g.dzhi[k+1]);
-        TF fac;
-        if (!sm) fac = sq(mlen0[k]);
-        else if (neutral) fac = sq(TF(1.)/(TF(1.)/mlen0[k] + TF(1.)/(TF(0.4)*(g.z[k]+z0m[ij]))));
-        else fac = sq(dsqrt2(TF(1.)/(TF(1.)/sq(mlen0[k]) + TF(1.)/sq(TF(0.4)*(g.z[k]+z0m[ij])))));
-        if (neutral) { ev[c] = fac * dsqrt2(s2); return; }
-        TF n2;
-        if (mo) n2 = dbdz[ij];
-        else if (N2) n2 = N2[c];
-        else n2 = grav/thref[k]*TF(0.5)*(th[c+g.ijcells] - th[c-g.ijcells])*g.dzi[k];
-        TF rit = n2 / s2 / tPr;
-        rit = tmin(rit, TF(1.-1.e-9));
-        ev[c] = fac * dsqrt2(s2) * dsqrt2(TF(1.)-rit);
+        TF n2 = TF(0);
+        if (!neutral)
+        {
+            if (mo) n2 = dbdz[ij];
+            else if (N2) n2 = N2[c];
+            else n2 = grav/thref[k]*TF(0.5)*(th[c+g.ijcells] - th[c-g.ijcells])*g.dzi[k];
+        }
+        ev[c] = evisc_value(s2, n2, sm, neutral, mlen0[k], sm ? g.z[k] : TF(0), sm ? z0m[ij] : TF(0), tPr);
     }
 };
 template<class TF>
@@ -166,9 +160,12 @@ MHH_API int mhh_diff_exec_viscosity(const mhh_grid* g, int scheme, const mhh_fie
     MHH_REQUIRE(!(p->neutral && !p->surface_model), "neutral + resolved walls: use mhh_smag2_strain2 + mhh_smag2_evisc_neutral");
     MHH_REQUIRE(!p->evisc_ghost_rows || g->jgc >= 2, "evisc_ghost_rows needs jgc >= 2");
     hipStream_t st = as_stream(stream);
+    // interior: the k-marching LDS kernel (k_visc.hip) where the layout allows LDS-DMA, else one thread per cell
+    const int marched = mhh_visc_march(g, f, p, th, stream);
 #define CALL(TF) [&]{ ViscosityOp<TF> op{make_grid<TF>(g), p->surface_model, p->neutral, mp<TF>(f->evisc), cp<TF>(f->u), cp<TF>(f->v), cp<TF>(f->w), \
                           cp<TF>(f->dudz), cp<TF>(f->dvdz), cp<TF>(f->dbdz), cp<TF>(f->z0m), cp<TF>(p->N2), cp<TF>(th), cp<TF>(p->thref), TF(p->grav), cp<TF>(p->mlen0), TF(p->tPr)}; \
-                      if (int e = launch_interior(st, op.g, g->kstart, g->kend, op)) return e; \
+                      if (marched < 0) return -marched; \
+                      if (!marched) if (int e = launch_interior(st, op.g, g->kstart, g->kend, op)) return e; \
                       if (p->evisc_ghost_rows) { \
                           if (int e = launch_cells(st, op, g->istart, g->iend, g->jstart-1, g->jstart, g->kstart, g->kend, g->icells, g->ijcells)) return e; \
                           if (int e = launch_cells(st, op, g->istart, g->iend, g->jend, g->jend+1, g->kstart, g->kend, g->icells, g->ijcells)) return e; } \

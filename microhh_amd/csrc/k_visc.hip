@@ -1,0 +1,204 @@
+// k_visc.hip -- Diff_smag2::exec_viscosity (strain^2 -> N2 -> evisc, src/diff_smag2.cxx:47-155,254-367) as a k-marching
+// LDS kernel for gfx950, the companion of k_march.hip.
+//
+// The one-thread-per-cell form (ViscosityOp, k_rhs.hip) issues 26 vector loads per cell, most of them one element off a
+// 512-byte row, and is bound by the L1/TA pipe (2.25 ms at 512^3 fp64 for 40 B/cell of algorithmic traffic). Here a
+// 64 x NJ block walks up in k: the planes k and k+1 of u, v, w live in LDS with a one-cell halo (LDS-DMA, one barrier
+// per level), and the four vertical-shear terms on the top face of level k are carried to level k+1 as its bottom-face
+// terms -- the two expressions have the same operands in the same order (src/diff_smag2.cxx:138-148), so the sum is the
+// reference's, bit for bit.
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include "k_common.h"
+#include "k_march_common.h"
+#include <gfx950_prims.h>
+
+using namespace mhh;
+
+namespace
+{
+template<class TF> struct ViscFields
+{
+    const TF* __restrict__ u; const TF* __restrict__ v; const TF* __restrict__ w; TF* __restrict__ ev;
+    const TF* __restrict__ dudz; const TF* __restrict__ dvdz; const TF* __restrict__ dbdz; const TF* __restrict__ z0m;
+    const TF* __restrict__ N2; const TF* __restrict__ th; const TF* __restrict__ thref; const TF* __restrict__ mlen0;
+    TF grav, tPr; int sm, neutral, ex;
+};
+
+#ifndef MHH_VISC_OCC
+#define MHH_VISC_OCC 4
+#endif
+#ifndef MHH_VISC_KC
+#define MHH_VISC_KC 64
+#endif
+template<class TF, int NJ>
+__global__ void __launch_bounds__(64*NJ, MHH_VISC_OCC) visc_march_kernel(const GridDev<TF> g, const ViscFields<TF> f, const MarchTiling mt)
+{
+    constexpr int VEC = 16 / (int)sizeof(TF);
+    constexpr int TI = 72, TJ = NJ + 2, NT = 64*NJ, NTILE = TI*TJ;    // tile x from i0-ex (ex <= 4: 64 + ex + 1 <= 72)
+    constexpr int R = 3;                                              // ring: planes k, k+1 and the copy in flight
+    __shared__ __attribute__((aligned(16))) TF U[R][NTILE];
+    __shared__ __attribute__((aligned(16))) TF V[R][NTILE];
+    __shared__ __attribute__((aligned(16))) TF W[R][NTILE];
+
+    int bx, by, kcn;
+    if (!decode_march(mt, blockIdx.x, bx, by, kcn)) return;
+    const int jj = g.icells, kk = g.ijcells;
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty*64 + tx;
+    const int i0 = g.istart + bx*64, j0 = g.jstart + by*NJ;
+    const int kb = g.kstart + kcn*mt.kc;
+    const int ke = (kb + mt.kc < g.kend) ? kb + mt.kc : g.kend;
+    const int i = i0 + tx, j = j0 + ty;
+    const bool active = (i < g.iend) && (j < g.jend);
+    const int ci = (i < g.iend) ? i : g.iend-1, cj = (j < g.jend) ? j : g.jend-1;
+    const int col = ci + cj*jj, ij = col;
+    const int l = (ty+1)*TI + (tx+f.ex);
+    auto slot = [](int p) { return (p + 12) % R; };
+
+    // tile pieces of 16 bytes: e = tid + n*NT -> (row, first column)
+    constexpr int PPR = TI / VEC, NP = PPR*TJ, NLD = (NP + NT - 1) / NT;
+    int off[NLD]; bool okt[NLD];
+#pragma unroll
+    for (int n=0; n<NLD; ++n)
+    {
+        const int e = tid + n*NT;
+        const int tj = e / PPR, ti = (e - tj*PPR)*VEC;
+        const int gi = i0 - f.ex + ti, gj = j0 - 1 + tj;
+        okt[n] = (e < NP) && (gi + VEC <= g.icells) && (gj < g.jcells);
+        off[n] = okt[n] ? gi + gj*jj : 0;
+    }
+    const int wave_e0 = tid & ~63;
+    auto dma_tile = [&](const TF* __restrict__ fld, int kp, TF* __restrict__ lds)
+    {
+        if (kp < 0 || kp >= g.kcells) return;                         // wave-uniform
+        const TF* __restrict__ pl = fld + (size_t)kp*kk;
+#pragma unroll
+        for (int n=0; n<NLD; ++n)
+            if (okt[n]) lds_dma16(pl + off[n], lds + (size_t)(wave_e0 + n*NT)*VEC);
+    };
+    auto colth = [&](int kp) -> TF { return (f.th && kp >= 0 && kp < g.kcells) ? f.th[col + kp*kk] : TF(0); };
+
+    // ---- prologue: planes ks and ks+1; ks = kb-1 is the warm-up level (only top-face terms are formed there) ----------
+    const int ks = kb - 1;
+    for (int p = ks; p <= ks+1; ++p)
+    {
+        dma_tile(f.u, p, U[slot(p)]); dma_tile(f.v, p, V[slot(p)]); dma_tile(f.w, p, W[slot(p)]);
+    }
+    TF thm = colth(ks-1), thc = colth(ks), thp = colth(ks+1);         // th at k-1, k, k+1 of this column
+    wait_vmem();
+    __syncthreads();
+
+    TF bu0 = 0, bu1 = 0, bv0 = 0, bv1 = 0;                            // carried bottom-face terms (already x 0.125)
+    // The result of level k is stored at the top of iteration k+1, after the next copy has been issued: s_waitcnt vmcnt(0)
+    // before the barrier also waits for stores (gfx9 has one counter), and a store issued right before it would expose its
+    // full latency on every level.
+    TF ev_pending = 0; int c_pending = -1;
+    const TF dxi = g.dxi_d, dyi = g.dyi_d;
+
+    for (int k = ks; k < ke; ++k)
+    {
+        const bool more = (k + 1 < ke);
+        if (more) { dma_tile(f.u, k+2, U[slot(k+2)]); dma_tile(f.v, k+2, V[slot(k+2)]); dma_tile(f.w, k+2, W[slot(k+2)]); }
+        const TF thn = more ? colth(k+2) : TF(0);
+        if (c_pending >= 0) { f.ev[c_pending] = ev_pending; c_pending = -1; }
+
+        const TF* __restrict__ uk = U[slot(k)] + l;  const TF* __restrict__ ukp = U[slot(k+1)] + l;
+        const TF* __restrict__ vk = V[slot(k)] + l;  const TF* __restrict__ vkp = V[slot(k+1)] + l;
+        const TF* __restrict__ wk = W[slot(k)] + l;  const TF* __restrict__ wkp = W[slot(k+1)] + l;
+        const TF dzhip = g.dzhi[k+1];
+
+        // top-face shear terms of level k == bottom-face terms of level k+1 (src/diff_smag2.cxx:140-141,146-147 vs :138-139,144-145)
+        const TF tu0 = TF(0.125)*sq((ukp[0 ]-uk[0 ])*dzhip + (wkp[0 ]-wkp[-1 ])*dxi);
+        const TF tu1 = TF(0.125)*sq((ukp[1 ]-uk[1 ])*dzhip + (wkp[1 ]-wkp[0  ])*dxi);
+        const TF tv0 = TF(0.125)*sq((vkp[0 ]-vk[0 ])*dzhip + (wkp[0 ]-wkp[-TI])*dyi);
+        const TF tv1 = TF(0.125)*sq((vkp[TI]-vk[TI])*dzhip + (wkp[TI]-wkp[0  ])*dyi);
+
+        if (k >= kb && active)
+        {
+            const bool mo = f.sm && (k == g.kstart);
+            TF acc = sq((uk[1]-uk[0])*dxi);
+            acc = acc + sq((vk[TI]-vk[0])*dyi);
+            acc = acc + sq((wkp[0]-wk[0])*g.dzi[k]);
+            acc = acc + TF(0.125)*sq((uk[0    ]-uk[-TI  ])*dyi + (vk[0   ]-vk[-1   ])*dxi);
+            acc = acc + TF(0.125)*sq((uk[1    ]-uk[1-TI ])*dyi + (vk[1   ]-vk[0    ])*dxi);
+            acc = acc + TF(0.125)*sq((uk[TI   ]-uk[0    ])*dyi + (vk[TI  ]-vk[TI-1 ])*dxi);
+            acc = acc + TF(0.125)*sq((uk[1+TI ]-uk[1    ])*dyi + (vk[1+TI]-vk[TI   ])*dxi);
+            if (mo)
+            {   // unresolved wall: MOST gradients replace the resolved du/dz, dv/dz (src/diff_smag2.cxx:72-114)
+                acc = acc + TF(0.5)*sq(f.dudz[ij]);
+                acc = acc + TF(0.125)*sq((wk [0 ]-wk [-1 ])*dxi);
+                acc = acc + TF(0.125)*sq((wk [1 ]-wk [0  ])*dxi);
+                acc = acc + TF(0.125)*sq((wkp[0 ]-wkp[-1 ])*dxi);
+                acc = acc + TF(0.125)*sq((wkp[1 ]-wkp[0  ])*dxi);
+                acc = acc + TF(0.5)*sq(f.dvdz[ij]);
+                acc = acc + TF(0.125)*sq((wk [0 ]-wk [-TI])*dyi);
+                acc = acc + TF(0.125)*sq((wk [TI]-wk [0  ])*dyi);
+                acc = acc + TF(0.125)*sq((wkp[0 ]-wkp[-TI])*dyi);
+                acc = acc + TF(0.125)*sq((wkp[TI]-wkp[0  ])*dyi);
+            }
+            else
+            {
+                acc = acc + bu0; acc = acc + bu1; acc = acc + tu0; acc = acc + tu1;
+                acc = acc + bv0; acc = acc + bv1; acc = acc + tv0; acc = acc + tv1;
+            }
+            TF s2 = TF(2.)*acc;
+            s2 += 1.e-9;
+            const int c = col + k*kk;
+            TF n2 = TF(0);
+            if (!f.neutral)
+            {
+                if (mo) n2 = f.dbdz[ij];
+                else if (f.N2) n2 = f.N2[c];
+                else n2 = f.grav/f.thref[k]*TF(0.5)*(thp - thm)*g.dzi[k];
+            }
+            c_pending = c;
+            ev_pending = evisc_value(s2, n2, f.sm, f.neutral, f.mlen0[k], f.sm ? g.z[k] : TF(0), f.sm ? f.z0m[ij] : TF(0), f.tPr);
+        }
+        bu0 = tu0; bu1 = tu1; bv0 = tv0; bv1 = tv1;
+        if (more)
+        {
+            wait_vmem();
+            __syncthreads();
+            thm = thc; thc = thp; thp = thn;
+        }
+    }
+    if (c_pending >= 0) f.ev[c_pending] = ev_pending;
+}
+
+template<class TF>
+int visc_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, const void* th, int ex, hipStream_t st)
+{
+    constexpr int NJ = 4;
+    ViscFields<TF> vf;
+    vf.u = cp<TF>(f->u); vf.v = cp<TF>(f->v); vf.w = cp<TF>(f->w); vf.ev = mp<TF>(f->evisc);
+    vf.dudz = cp<TF>(f->dudz); vf.dvdz = cp<TF>(f->dvdz); vf.dbdz = cp<TF>(f->dbdz); vf.z0m = cp<TF>(f->z0m);
+    vf.N2 = cp<TF>(p->N2); vf.th = cp<TF>(th); vf.thref = cp<TF>(p->thref); vf.mlen0 = cp<TF>(p->mlen0);
+    vf.grav = TF(p->grav); vf.tPr = TF(p->tPr); vf.sm = p->surface_model; vf.neutral = p->neutral; vf.ex = ex;
+    const MarchTiling t = make_march_tiling(g, NJ, MHH_VISC_KC);
+    hipLaunchKernelGGL((visc_march_kernel<TF, NJ>), dim3(march_blocks(t)), dim3(64, NJ), 0, st, make_grid<TF>(g), vf, t);
+    MHH_LAUNCH_CHECK();
+    return MHH_OK;
+}
+} // namespace
+
+static unsigned long long g_visc_march_launches = 0;
+// diagnostics: how many times the marching form (as opposed to the one-thread-per-cell form) has been launched
+MHH_API unsigned long long mhh_stat_visc_march_launches(void) { return g_visc_march_launches; }
+
+// Entry used by mhh_diff_exec_viscosity (inputs validated there). Returns 1 when the marching kernel ran, 0 when the
+// layout does not meet the LDS-DMA alignment rules (the caller then takes the cell kernel), < 0 on error (-code).
+int mhh_visc_march(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, const void* th, void* stream)
+{
+    { const char* e = getenv("MHH_VISC_IMPL"); if (e && !strcmp(e, "cell")) return 0; }     // A/B switch, read per call
+    const int vec = (g->dtype == MHH_F64) ? 2 : 4;
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+    if (g->icells % vec != 0 || !al16(f->u) || !al16(f->v) || !al16(f->w)) return 0;
+    // tile x-origin i0 - ex with i0 = igc + 64*bx must sit on a 16-byte boundary and cover i-1: 1 <= ex <= igc, (igc - ex) % vec == 0
+    int ex = 0;
+    for (int e = 1; e <= g->igc && e <= 4; ++e) if ((g->igc - e) % vec == 0) { ex = e; break; }
+    if (ex == 0 || g->jgc < 1 || g->kgc < 1) return 0;
+    ++g_visc_march_launches;
+    const int rc = (g->dtype == MHH_F64) ? visc_launch<double>(g, f, p, th, ex, as_stream(stream)) : visc_launch<float>(g, f, p, th, ex, as_stream(stream));
+    return rc == MHH_OK ? 1 : -rc;
+}

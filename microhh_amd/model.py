@@ -23,6 +23,8 @@ CASES = {
     # name: advec, diff, pres order, spatial order, ghost cells, domain, scalars, surface model
     "taylorgreen": dict(advec=ADVEC_2, diff=DIFF_2, pres=2, order=2, gc=(1, 1, 1), size=(1., 1., 0.5), nscalars=0, sm=0, visc=(8.*math.pi**2*1000.)**-1),
     "drycblles": dict(advec=ADVEC_2I5, diff=DIFF_SMAG2, pres=2, order=2, gc=(3, 3, 1), size=(3200., 3200., 1200.), nscalars=1, sm=1, visc=1e-5),
+    # gabls1 (cases/gabls1/gabls1.ini: cs = 0.1, 400 m domain at 32^2 columns, scaled with the column count)
+    "gabls1": dict(advec=ADVEC_2I5, diff=DIFF_SMAG2, pres=2, order=2, gc=(3, 3, 1), size=(12800., 12800., 400.), nscalars=1, sm=1, visc=1e-5, cs=0.1),
     "moser600": dict(advec=ADVEC_4, diff=DIFF_4, pres=4, order=4, gc=(3, 3, 3), size=(2*math.pi, math.pi, 2.), nscalars=0, sm=0, visc=1e-5),
 }
 
@@ -117,7 +119,7 @@ class HotPath:
         self.work = torch.zeros(16, device=self.device, dtype=torch.float64)
         # Diff_smag2::prepare_device: per-level mixing-length table from the host libm
         self.params = p = capi.MhhDiffParams()
-        p.cs, p.tPr, p.surface_model, p.neutral, p.N2, p.th_for_N2, p.grav = 0.23, 1./3., cfg["sm"], 0, None, 0, 9.81
+        p.cs, p.tPr, p.surface_model, p.neutral, p.N2, p.th_for_N2, p.grav = cfg.get("cs", 0.23), 1./3., cfg["sm"], 0, None, 0, 9.81
         p.thref = self.thref.data_ptr()
         if cfg["diff"] == DIFF_SMAG2:
             ml = np.zeros(g.kcells, dtype=g.np_dtype)

@@ -335,6 +335,35 @@ def test_exec_viscosity(be, sm, neutral, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("sm,neutral", [(1, 0), (0, 0), (1, 1)])
+def test_exec_viscosity_marching_form_equals_cell_form(be, sm, neutral, dtype):
+    """k_visc.hip (LDS planes, carried vertical-shear terms) against the one-thread-per-cell ViscosityOp: the same bits,
+    on tiles that are cut by the domain edge, several k-chunks, and layouts that do / do not allow LDS-DMA."""
+    shapes = [(70, 10, 12), (16, 12, 131), (18, 9, 8)] if dtype == np.float64 else [(70, 10, 12), (18, 9, 8), (16, 12, 10)]
+    for shape in shapes:
+        g = cm.grid_2nd(*shape, gc=(3, 3, 1), dtype=dtype)
+        c = cm.Case(g, periodic=True)
+        thref = np.full(g.kcells, 300., dtype=dtype)
+        out = {}
+        for impl in ("march", "cell"):
+            d = B.DevCase(be, c); f = d.fields()
+            p = capi.MhhDiffParams(); p.cs = 0.23; p.tPr = 1./3.; p.surface_model = sm; p.neutral = neutral
+            p.N2 = None; p.th_for_N2 = 0; dthref = be.arr(thref); p.thref = be.ptr(dthref).value; p.grav = 9.81
+            ml = B.mlen0(be, g, 0.23); p.mlen0 = be.ptr(ml).value
+            os.environ["MHH_VISC_IMPL"] = impl
+            try:
+                n0 = be.lib.mhh_stat_visc_march_launches()
+                B.ok(be, be.lib.mhh_diff_exec_viscosity(d.G, cm.DIFF_SMAG2, C.byref(f), C.byref(p), be.stream))
+                ran = be.lib.mhh_stat_visc_march_launches() - n0
+            finally:
+                del os.environ["MHH_VISC_IMPL"]
+            out[impl] = be.host(d.evisc)
+            aligned = g.icells % (2 if dtype == np.float64 else 4) == 0
+            assert ran == (1 if (impl == "march" and aligned) else 0), (impl, shape, ran)
+        assert same(out["march"], out["cell"]), (shape, cm.ulp_diff(out["march"], out["cell"]))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("order", [2, 4])
 def test_pres(be, order, dtype):
     O = cm.oracle()
