@@ -204,6 +204,7 @@ int mhh_diff_exec_viscosity(const mhh_grid* g, int scheme, const mhh_fields* f, 
 /* diagnostic: launches of the k-marching form of exec_viscosity so far (it needs 16-byte aligned rows; other layouts
  * take the one-thread-per-cell kernel, same bits) */
 unsigned long long mhh_stat_visc_march_launches(void);
+unsigned long long mhh_stat_rhs44_march_launches(void);   /* same for the k-marching form of (advec_4, diff_4) in mhh_rhs_exec */
 int mhh_diff_exec(const mhh_grid* g, int scheme, const mhh_fields* f, const mhh_diff_params* p, void* stream);
 
 /* Thermo_dry::exec buoyancy tendency, calc_buoyancy_tend_2nd / _4th (src/thermo_dry.cxx:165-197,

@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["k_stencil.hip", "k_rhs.hip", "k_march.hip", "k_visc.hip", "k_pres.hip", "k_slab.hip"]
+SOURCES = ["k_stencil.hip", "k_rhs.hip", "k_march.hip", "k_march4.hip", "k_visc.hip", "k_pres.hip", "k_slab.hip"]
 LIB = os.path.join(HERE, "libmhh_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: no FMA contraction, so that every stencil rounds like the reference CPU path built

@@ -51,6 +51,7 @@ SIGNATURES = {
     "mhh_advec_s_lim": (ci, [GP, vp, vp, vp, vp, vp, vp, vp, vp]),
     "mhh_advec_exec": (ci, [GP, ci, FP, vp]),
     "mhh_stat_visc_march_launches": (C.c_ulonglong, []),
+    "mhh_stat_rhs44_march_launches": (C.c_ulonglong, []),
     "mhh_thermo_dry_buoyancy_tend": (ci, [GP, ci, vp, vp, vp, cd, vp]),
     "mhh_advec_cfl": (ci, [GP, ci, vp, vp, vp, cd, vp, C.POINTER(cd), vp]),
     "mhh_diff_c": (ci, [GP, ci, vp, vp, cd, vp]),

@@ -204,45 +204,62 @@ MHH_HD TF advec_s_lim_cell(const TF* __restrict__ s, const TF* __restrict__ u, c
 // sd = staggering stride of the advected momentum component (1, jj, kk); is_w selects the w equation, whose
 // vertical advecting velocity is the advected field itself incl. the biased wall forms.
 // =======================================================================================================
+// The arithmetic is written once against a "view" of each field -- view.at<DI,DJ,DK>() = the value DI, DJ, DK cells away
+// from the cell being updated -- so that the one-thread-per-cell kernels (GlobalView: flat array) and the k-marching
+// kernel (k_march4.hip: LDS planes for horizontal offsets, a register window for the own column) execute the very same
+// expressions.
+template<class TF> struct GlobalView
+{
+    const TF* __restrict__ p; int c, jj, kk;
+    template<int DI, int DJ, int DK> MHH_HD TF at() const { return p[c + DI + DJ*jj + DK*kk]; }
+};
+// 4th-order interpolation of `a` to the location of momentum component COMP (along its staggering direction), evaluated
+// at the cell (SI, SJ, SK) away: a[-2e], a[-e], a[0], a[+e] with e the unit vector of COMP
+template<int COMP, int SI, int SJ, int SK, class TF, class V>
+MHH_HD TF stag_ci4(const V& a)
+{
+    constexpr int EI = (COMP == 0), EJ = (COMP == 1), EK = (COMP == 2);
+    return ci4<TF>(a.template at<SI-2*EI, SJ-2*EJ, SK-2*EK>(), a.template at<SI-EI, SJ-EJ, SK-EK>(),
+                   a.template at<SI, SJ, SK>(), a.template at<SI+EI, SJ+EJ, SK+EK>());
+}
+template<int COMP, int M, class TF, class FV, class UV>
+MHH_HD TF advec4_px(const FV& f, const UV& u)
+{ return stag_ci4<COMP, M-1, 0, 0, TF>(u) * ci4<TF>(f.template at<M-3,0,0>(), f.template at<M-2,0,0>(), f.template at<M-1,0,0>(), f.template at<M,0,0>()); }
+template<int COMP, int M, class TF, class FV, class VV>
+MHH_HD TF advec4_py(const FV& f, const VV& v)
+{ return stag_ci4<COMP, 0, M-1, 0, TF>(v) * ci4<TF>(f.template at<0,M-3,0>(), f.template at<0,M-2,0>(), f.template at<0,M-1,0>(), f.template at<0,M,0>()); }
+template<int COMP, int M, class TF, class FV, class WV>
+MHH_HD TF advec4_pz(const FV& f, const WV& w, bool bot, bool top)
+{
+    TF fi;
+    if (M == 0 && bot)      fi = bi4<TF>(f.template at<0,0,-2>(), f.template at<0,0,-1>(), f.template at<0,0,0>(), f.template at<0,0,1>());
+    else if (M == 3 && top) fi = ti4<TF>(f.template at<0,0,-1>(), f.template at<0,0,0>(), f.template at<0,0,1>(), f.template at<0,0,2>());
+    else                    fi = ci4<TF>(f.template at<0,0,M-3>(), f.template at<0,0,M-2>(), f.template at<0,0,M-1>(), f.template at<0,0,M>());
+    TF ve;
+    if constexpr (COMP == 2) ve = fi;                        // the w equation advects itself vertically
+    else                     ve = stag_ci4<COMP, 0, 0, M-1, TF>(w);
+    return ve * fi;
+}
+// COMP = 0, 1, 2: the u, v, w equation; f is the advected component itself (u, v or w)
+template<int COMP, class TF, class FV, class UV, class VV, class WV>
+MHH_HD void advec4_mom_v(TF d[3], const FV& f, const UV& u, const VV& v, const WV& w, bool bot, bool top, TF dxi, TF dyi, TF dz, bool dim3)
+{
+    const TF cg0 = TF(1./24.), cg1 = TF(-27./24.), cg2 = TF(27./24.), cg3 = TF(-1./24.);
+    d[0] = ( cg0*advec4_px<COMP,0,TF>(f, u) + cg1*advec4_px<COMP,1,TF>(f, u) + cg2*advec4_px<COMP,2,TF>(f, u) + cg3*advec4_px<COMP,3,TF>(f, u) ) * dxi;
+    d[1] = TF(0);
+    if (dim3)
+        d[1] = ( cg0*advec4_py<COMP,0,TF>(f, v) + cg1*advec4_py<COMP,1,TF>(f, v) + cg2*advec4_py<COMP,2,TF>(f, v) + cg3*advec4_py<COMP,3,TF>(f, v) ) * dyi;
+    d[2] = ( cg0*advec4_pz<COMP,0,TF>(f, w, bot, top) + cg1*advec4_pz<COMP,1,TF>(f, w, bot, top)
+           + cg2*advec4_pz<COMP,2,TF>(f, w, bot, top) + cg3*advec4_pz<COMP,3,TF>(f, w, bot, top) ) * dz;
+}
 template<class TF>
 MHH_HD void advec4_mom(TF d[3], const TF* __restrict__ f, const TF* __restrict__ u, const TF* __restrict__ v, const TF* __restrict__ w,
                        int c, int sd, bool is_w, int jj, int kk, bool bot, bool top, TF dxi, TF dyi, TF dz, bool dim3)
 {
-    const TF cg0 = TF(1./24.), cg1 = TF(-27./24.), cg2 = TF(27./24.), cg3 = TF(-1./24.);
-    {
-        TF p[4];
-        for (int m=0; m<4; ++m)
-        {
-            const int b = c + (m-1);
-            p[m] = ci4(u[b-2*sd], u[b-sd], u[b], u[b+sd]) * ci4(f[c+m-3], f[c+m-2], f[c+m-1], f[c+m]);
-        }
-        d[0] = ( cg0*p[0] + cg1*p[1] + cg2*p[2] + cg3*p[3] ) * dxi;
-    }
-    d[1] = TF(0);
-    if (dim3)
-    {
-        TF p[4];
-        for (int m=0; m<4; ++m)
-        {
-            const int b = c + (m-1)*jj;
-            p[m] = ci4(v[b-2*sd], v[b-sd], v[b], v[b+sd]) * ci4(f[c+(m-3)*jj], f[c+(m-2)*jj], f[c+(m-1)*jj], f[c+m*jj]);
-        }
-        d[1] = ( cg0*p[0] + cg1*p[1] + cg2*p[2] + cg3*p[3] ) * dyi;
-    }
-    {
-        TF p[4];
-        for (int m=0; m<4; ++m)
-        {
-            const int b = c + (m-1)*kk;
-            TF fi;
-            if (bot && m==0)      fi = bi4(f[c-2*kk], f[c-kk], f[c], f[c+kk]);
-            else if (top && m==3) fi = ti4(f[c-kk], f[c], f[c+kk], f[c+2*kk]);
-            else                  fi = ci4(f[c+(m-3)*kk], f[c+(m-2)*kk], f[c+(m-1)*kk], f[c+m*kk]);
-            const TF ve = is_w ? fi : ci4(w[b-2*sd], w[b-sd], w[b], w[b+sd]);
-            p[m] = ve * fi;
-        }
-        d[2] = ( cg0*p[0] + cg1*p[1] + cg2*p[2] + cg3*p[3] ) * dz;
-    }
+    const GlobalView<TF> fv{f, c, jj, kk}, uv{u, c, jj, kk}, vv{v, c, jj, kk}, wv{w, c, jj, kk};
+    if (is_w)          advec4_mom_v<2>(d, fv, uv, vv, wv, bot, top, dxi, dyi, dz, dim3);
+    else if (sd == 1)  advec4_mom_v<0>(d, fv, uv, vv, wv, bot, top, dxi, dyi, dz, dim3);
+    else               advec4_mom_v<1>(d, fv, uv, vv, wv, bot, top, dxi, dyi, dz, dim3);
 }
 template<class TF>
 MHH_HD void advec4_s(TF d[3], const TF* __restrict__ s, const TF* __restrict__ u, const TF* __restrict__ v, const TF* __restrict__ w,
@@ -304,22 +321,32 @@ MHH_HD TF diff2_apply(TF t, const TF* __restrict__ a, int c, int jj, int kk, TF 
 // =======================================================================================================
 // diff_4 (src/diff_4.cxx:41-173): three increments. g4[0..3] = inner metric at the four faces, go = outer metric.
 // =======================================================================================================
+template<class TF, class AV>
+MHH_HD void diff4_v(TF d[3], const AV& a, bool bot, bool top, TF visc, TF dxidxi, TF dyidyi, const TF g4[4], TF go, bool dim3)
+{
+    const TF cdg0 = TF(-1460./576.), cdg1 = TF(783./576.), cdg2 = TF(-54./576.), cdg3 = TF(1./576.);
+    const TF cg0 = TF(1./24.), cg1 = TF(-27./24.), cg2 = TF(27./24.), cg3 = TF(-1./24.);
+    d[0] = visc * (cdg3*a.template at<-3,0,0>() + cdg2*a.template at<-2,0,0>() + cdg1*a.template at<-1,0,0>() + cdg0*a.template at<0,0,0>()
+                 + cdg1*a.template at<1,0,0>() + cdg2*a.template at<2,0,0>() + cdg3*a.template at<3,0,0>())*dxidxi;
+    d[1] = TF(0);
+    if (dim3)
+        d[1] = visc * (cdg3*a.template at<0,-3,0>() + cdg2*a.template at<0,-2,0>() + cdg1*a.template at<0,-1,0>() + cdg0*a.template at<0,0,0>()
+                     + cdg1*a.template at<0,1,0>() + cdg2*a.template at<0,2,0>() + cdg3*a.template at<0,3,0>())*dyidyi;
+    const TF g0 = bot ? bg4<TF>(a.template at<0,0,-2>(), a.template at<0,0,-1>(), a.template at<0,0,0>(), a.template at<0,0,1>())
+                      : cg4<TF>(a.template at<0,0,-3>(), a.template at<0,0,-2>(), a.template at<0,0,-1>(), a.template at<0,0,0>());
+    const TF g3 = top ? tg4<TF>(a.template at<0,0,-1>(), a.template at<0,0,0>(), a.template at<0,0,1>(), a.template at<0,0,2>())
+                      : cg4<TF>(a.template at<0,0,0>(), a.template at<0,0,1>(), a.template at<0,0,2>(), a.template at<0,0,3>());
+    d[2] = visc * ( cg0*g0 * g4[0]
+                  + cg1*cg4<TF>(a.template at<0,0,-2>(), a.template at<0,0,-1>(), a.template at<0,0,0>(), a.template at<0,0,1>()) * g4[1]
+                  + cg2*cg4<TF>(a.template at<0,0,-1>(), a.template at<0,0,0>(), a.template at<0,0,1>(), a.template at<0,0,2>()) * g4[2]
+                  + cg3*g3 * g4[3] ) * go;
+}
 template<class TF>
 MHH_HD void diff4_cell(TF d[3], const TF* __restrict__ a, int c, int jj, int kk, bool bot, bool top, TF visc,
                        TF dxidxi, TF dyidyi, const TF g4[4], TF go, bool dim3)
 {
-    const TF cdg0 = TF(-1460./576.), cdg1 = TF(783./576.), cdg2 = TF(-54./576.), cdg3 = TF(1./576.);
-    const TF cg0 = TF(1./24.), cg1 = TF(-27./24.), cg2 = TF(27./24.), cg3 = TF(-1./24.);
-    d[0] = visc * (cdg3*a[c-3] + cdg2*a[c-2] + cdg1*a[c-1] + cdg0*a[c] + cdg1*a[c+1] + cdg2*a[c+2] + cdg3*a[c+3])*dxidxi;
-    d[1] = TF(0);
-    if (dim3)
-        d[1] = visc * (cdg3*a[c-3*jj] + cdg2*a[c-2*jj] + cdg1*a[c-jj] + cdg0*a[c] + cdg1*a[c+jj] + cdg2*a[c+2*jj] + cdg3*a[c+3*jj])*dyidyi;
-    const TF g0 = bot ? bg4(a[c-2*kk], a[c-kk], a[c], a[c+kk]) : cg4(a[c-3*kk], a[c-2*kk], a[c-kk], a[c]);
-    const TF g3 = top ? tg4(a[c-kk], a[c], a[c+kk], a[c+2*kk]) : cg4(a[c], a[c+kk], a[c+2*kk], a[c+3*kk]);
-    d[2] = visc * ( cg0*g0 * g4[0]
-                  + cg1*cg4(a[c-2*kk], a[c-kk], a[c], a[c+kk]) * g4[1]
-                  + cg2*cg4(a[c-kk], a[c], a[c+kk], a[c+2*kk]) * g4[2]
-                  + cg3*g3 * g4[3] ) * go;
+    const GlobalView<TF> av{a, c, jj, kk};
+    diff4_v(d, av, bot, top, visc, dxidxi, dyidyi, g4, go, dim3);
 }
 
 // =======================================================================================================

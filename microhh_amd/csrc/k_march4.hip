@@ -1,0 +1,197 @@
+// k_march4.hip -- advec_4 + diff_4 for u, v, w in ONE pass as a k-marching LDS kernel (src/advec_4.cxx:88-486,
+// src/diff_4.cxx:41-173), the 4th-order sibling of k_march.hip.
+//
+// The one-thread-per-cell form (Rhs44Op, k_rhs.hip) issues 175 vector loads per cell and is bound by the L1/TA pipe
+// (3.3 ms at 512x256x256 fp64 for 72 B/cell of algorithmic traffic). Here a 64 x NJ block walks up in k with the planes
+// that are read with horizontal offsets in LDS (halo 3): u, v at k-2..k+1 (the w equation interpolates them vertically
+// at x / y offsets), w at k-1..k+2 (the u and v equations interpolate it horizontally at four levels); the 7-level
+// column of each thread's own u, v, w sits in registers. The arithmetic is the view-generic code of cell_ops.h
+// (advec4_mom_v, diff4_v), i.e. literally the expressions of the cell kernel: same bits.
+//
+// LDS budget: u and v keep exactly their four planes -- the w equation, the only reader of the oldest one, is computed
+// first, then a barrier, then the copy of plane k+2 is issued into that slot and lands while the u and v equations are
+// computed; w has a fifth slot for its copy. 13 planes of 70 x (NJ+6) doubles = 72.8 KB: two blocks per CU.
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include "k_common.h"
+#include "k_march_common.h"
+#include <gfx950_prims.h>
+
+using namespace mhh;
+
+namespace
+{
+template<class TF> struct March4Fields
+{
+    const TF* __restrict__ u; const TF* __restrict__ v; const TF* __restrict__ w;
+    TF* __restrict__ ut; TF* __restrict__ vt; TF* __restrict__ wt;
+    TF visc;
+};
+
+// field view of the marching kernel: horizontal offsets from the LDS plane of that level, the own column from registers
+template<class TF, int TI> struct MarchView
+{
+    const TF* pl[5];                 // plane pointers (already at this thread's cell) for level offsets -2..+2
+    const TF (&win)[7];              // own column, level offsets -3..+3
+    template<int DI, int DJ, int DK> __device__ __forceinline__ TF at() const
+    {
+        if constexpr (DI == 0 && DJ == 0) return win[3+DK];
+        else return pl[DK+2][DI + DJ*TI];
+    }
+};
+
+template<class TF> __device__ __forceinline__ void shift7(TF (&w)[7], TF nw)
+{
+    w[0] = w[1]; w[1] = w[2]; w[2] = w[3]; w[3] = w[4]; w[4] = w[5]; w[5] = w[6]; w[6] = nw;
+}
+
+#ifndef MHH_MARCH4_OCC
+#define MHH_MARCH4_OCC 2
+#endif
+#ifndef MHH_MARCH4_KC
+#define MHH_MARCH4_KC 64
+#endif
+
+template<class TF, int NJ>
+__global__ void __launch_bounds__(64*NJ, MHH_MARCH4_OCC) rhs44_march_kernel(const GridDev<TF> g, const March4Fields<TF> f, const MarchTiling mt)
+{
+    constexpr int VEC = 16 / (int)sizeof(TF);
+    constexpr int TI = ((70 + VEC-1)/VEC)*VEC, TJ = NJ + 6, NT = 64*NJ, NTILE = TI*TJ;
+    constexpr int RUV = 4, RW = 5;
+    __shared__ __attribute__((aligned(16))) TF U[RUV][NTILE];
+    __shared__ __attribute__((aligned(16))) TF V[RUV][NTILE];
+    __shared__ __attribute__((aligned(16))) TF W[RW][NTILE];
+
+    int bx, by, kcn;
+    if (!decode_march(mt, blockIdx.x, bx, by, kcn)) return;
+    const int jj = g.icells, kk = g.ijcells;
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty*64 + tx;
+    const int i0 = g.istart + bx*64, j0 = g.jstart + by*NJ;
+    const int kb = g.kstart + kcn*mt.kc;
+    const int ke = (kb + mt.kc < g.kend) ? kb + mt.kc : g.kend;
+    const int i = i0 + tx, j = j0 + ty;
+    const bool active = (i < g.iend) && (j < g.jend);
+    const int ci = (i < g.iend) ? i : g.iend-1, cj = (j < g.jend) ? j : g.jend-1;
+    const int col = ci + cj*jj;
+    const int l = (ty+3)*TI + (tx+3);
+    auto su = [](int p) { return (p + 16) % RUV; };
+    auto sw = [](int p) { return (p + 20) % RW; };
+
+    constexpr int PPR = TI / VEC, NP = PPR*TJ, NLD = (NP + NT - 1) / NT;
+    int off[NLD]; bool okt[NLD];
+#pragma unroll
+    for (int n=0; n<NLD; ++n)
+    {
+        const int e = tid + n*NT;
+        const int tj = e / PPR, ti = (e - tj*PPR)*VEC;
+        const int gi = i0 - 3 + ti, gj = j0 - 3 + tj;
+        okt[n] = (e < NP) && (gi + VEC <= g.icells) && (gj < g.jcells);
+        off[n] = okt[n] ? gi + gj*jj : 0;
+    }
+    const int wave_e0 = tid & ~63;
+    auto dma_tile = [&](const TF* __restrict__ fld, int kp, TF* __restrict__ lds)
+    {
+        if (kp < 0 || kp >= g.kcells) return;                         // wave-uniform
+        const TF* __restrict__ pl = fld + (size_t)kp*kk;
+#pragma unroll
+        for (int n=0; n<NLD; ++n)
+            if (okt[n]) lds_dma16(pl + off[n], lds + (size_t)(wave_e0 + n*NT)*VEC);
+    };
+    auto colval = [&](const TF* __restrict__ fld, int kp) -> TF { return (kp >= 0 && kp < g.kcells) ? fld[col + kp*kk] : TF(0); };
+
+    // ---- prologue: u, v planes kb-2..kb+1, w planes kb-1..kb+2, windows centred on kb ---------------------------------
+    for (int p = kb-2; p <= kb+1; ++p) { dma_tile(f.u, p, U[su(p)]); dma_tile(f.v, p, V[su(p)]); }
+    for (int p = kb-1; p <= kb+2; ++p) dma_tile(f.w, p, W[sw(p)]);
+    TF uw[7], vw[7], ww[7];
+#pragma unroll
+    for (int n=0; n<7; ++n) { uw[n] = colval(f.u, kb-3+n); vw[n] = colval(f.v, kb-3+n); ww[n] = colval(f.w, kb-3+n); }
+    wait_vmem();
+    __syncthreads();
+
+    const TF dxi = g.dxi_t, dyi = g.dyi_t;
+    const bool dim3 = g.dim3;
+    auto both = [&](TF t, const TF ad[3], const TF df[3]) -> TF
+    {
+        t -= ad[0]; if (dim3) t -= ad[1]; t -= ad[2];
+        t += df[0]; if (dim3) t += df[1]; t += df[2];
+        return t;
+    };
+
+    for (int k = kb; k < ke; ++k)
+    {
+        const bool more = (k + 1 < ke);
+        if (more) dma_tile(f.w, k+3, W[sw(k+3)]);
+        const TF nu = more ? colval(f.u, k+4) : TF(0), nv = more ? colval(f.v, k+4) : TF(0), nw = more ? colval(f.w, k+4) : TF(0);
+
+        const MarchView<TF, TI> Uv{{U[su(k-2)]+l, U[su(k-1)]+l, U[su(k)]+l, U[su(k+1)]+l, nullptr}, uw};
+        const MarchView<TF, TI> Vv{{V[su(k-2)]+l, V[su(k-1)]+l, V[su(k)]+l, V[su(k+1)]+l, nullptr}, vw};
+        const MarchView<TF, TI> Wv{{nullptr, W[sw(k-1)]+l, W[sw(k)]+l, W[sw(k+1)]+l, W[sw(k+2)]+l}, ww};
+        const bool bot = (k == g.kstart), top = (k == g.kend-1);
+        const int c = col + k*kk;
+        TF ad[3], df[3];
+
+        // ---- w equation first: the only reader of the u, v planes k-2 ---------------------------------------------------
+        if (active && k > g.kstart)
+        {
+            const bool botw = (k == g.kstart+1);
+            const TF gw4[4] = {g.dzi4[k-2], g.dzi4[k-1], g.dzi4[k], g.dzi4[k+1]};
+            advec4_mom_v<2>(ad, Wv, Uv, Vv, Wv, botw, top, dxi, dyi, g.dzhi4[k], dim3);
+            diff4_v(df, Wv, botw, top, f.visc, g.dxidxi_t, g.dyidyi_t, gw4, g.dzhi4[k], dim3);
+            f.wt[c] = both(f.wt[c], ad, df);
+        }
+        if (more)
+        {
+            __syncthreads();                                          // everyone is done with the u, v planes k-2
+            dma_tile(f.u, k+2, U[su(k+2)]); dma_tile(f.v, k+2, V[su(k+2)]);
+        }
+        // ---- u and v equations (planes k of u, v; k-1..k+2 of w) --------------------------------------------------------
+        if (active)
+        {
+            const TF gc4[4] = {g.dzhi4[k-1], g.dzhi4[k], g.dzhi4[k+1], g.dzhi4[k+2]};
+            advec4_mom_v<0>(ad, Uv, Uv, Vv, Wv, bot, top, dxi, dyi, g.dzi4[k], dim3);
+            diff4_v(df, Uv, bot, top, f.visc, g.dxidxi_d, g.dyidyi_d, gc4, g.dzi4[k], dim3);
+            f.ut[c] = both(f.ut[c], ad, df);
+            advec4_mom_v<1>(ad, Vv, Uv, Vv, Wv, bot, top, dxi, dyi, g.dzi4[k], dim3);
+            diff4_v(df, Vv, bot, top, f.visc, g.dxidxi_d, g.dyidyi_d, gc4, g.dzi4[k], dim3);
+            f.vt[c] = both(f.vt[c], ad, df);
+        }
+        if (more)
+        {
+            wait_vmem();
+            __syncthreads();
+            shift7(uw, nu); shift7(vw, nv); shift7(ww, nw);
+        }
+    }
+}
+
+template<class TF>
+int march4_launch(const mhh_grid* g, const mhh_fields* f, hipStream_t st)
+{
+    constexpr int NJ = 4;
+    March4Fields<TF> mf;
+    mf.u = cp<TF>(f->u); mf.v = cp<TF>(f->v); mf.w = cp<TF>(f->w);
+    mf.ut = mp<TF>(f->ut); mf.vt = mp<TF>(f->vt); mf.wt = mp<TF>(f->wt); mf.visc = TF(f->visc);
+    const MarchTiling t = make_march_tiling(g, NJ, MHH_MARCH4_KC);
+    hipLaunchKernelGGL((rhs44_march_kernel<TF, NJ>), dim3(march_blocks(t)), dim3(64, NJ), 0, st, make_grid<TF>(g), mf, t);
+    MHH_LAUNCH_CHECK();
+    return MHH_OK;
+}
+static unsigned long long g_rhs44_march_launches = 0;
+} // namespace
+
+MHH_API unsigned long long mhh_stat_rhs44_march_launches(void) { return g_rhs44_march_launches; }
+
+// Entry used by mhh_rhs_exec for (advec_4, diff_4): u, v, w only (scalars take the per-field kernels). Returns 1 when the
+// marching kernel ran, 0 when the layout does not meet the LDS-DMA alignment rules, < 0 on error (-code).
+int mhh_rhs44_march(const mhh_grid* g, const mhh_fields* f, void* stream)
+{
+    { const char* e = getenv("MHH_RHS44_IMPL"); if (e && !strcmp(e, "cell")) return 0; }
+    const int vec = (g->dtype == MHH_F64) ? 2 : 4;
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+    if (g->icells % vec != 0 || (g->igc - 3) % vec != 0 || g->igc < 3 || g->jgc < 3 || g->kgc < 3) return 0;
+    if (!al16(f->u) || !al16(f->v) || !al16(f->w)) return 0;
+    ++g_rhs44_march_launches;
+    const int rc = (g->dtype == MHH_F64) ? march4_launch<double>(g, f, as_stream(stream)) : march4_launch<float>(g, f, as_stream(stream));
+    return rc == MHH_OK ? 1 : -rc;
+}

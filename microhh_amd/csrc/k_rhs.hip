@@ -1,6 +1,7 @@
 // k_rhs.hip -- operator-level entry points: Diff::exec_viscosity, Diff::exec, the fused advec+diff RHS pass,
 // and the max-reductions behind get_cfl / get_dn / check_divergence. gfx950 only.
 #include <cstdlib>
+#include <cstdint>
 #include "k_common.h"
 #include <wave_reduce.h>   // angle form: the CPU emulation build (tests/emul) overrides it by include path
 
@@ -8,6 +9,7 @@ using namespace mhh;
 
 int mhh_rhs25_march(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, void* stream);   // k_march.hip
 int mhh_visc_march(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, const void* th, void* stream);   // k_visc.hip
+int mhh_rhs44_march(const mhh_grid* g, const mhh_fields* f, void* stream);                                           // k_march4.hip
 
 // =======================================================================================================
 // Max reductions (calc_cfl / calc_dnmul / calc_divergence + Master::max). All integrands are |.| >= 0, so the
@@ -438,6 +440,30 @@ MHH_API int mhh_rhs_exec(const mhh_grid* g, int advec_scheme, int diff_scheme, c
     if (advec_scheme == MHH_ADVEC_4 && diff_scheme == MHH_DIFF_4)
     {
         MHH_REQUIRE(g->igc >= 3 && g->jgc >= 3 && g->kgc >= 3, "4th order needs gc(3,3,3)");
+        // default: the k-marching LDS kernel (k_march4.hip) for u, v, w where the rows allow LDS-DMA; scalars and the folded
+        // buoyancy then take their own kernels (same order of accumulation). MHH_RHS44_IMPL=cell selects the cell kernel.
+        {
+            const mhh_fields* fq = f;
+            const bool buoy = p && p->buoyancy;
+            // probe the layout first so that the buoyancy term is added exactly once, and before advection
+            const char* e = getenv("MHH_RHS44_IMPL");
+            const int vec = (g->dtype == MHH_F64) ? 2 : 4;
+            const bool can = !(e && !strcmp(e, "cell")) && g->icells % vec == 0 && (g->igc - 3) % vec == 0
+                             && !((uintptr_t)f->u & 15u) && !((uintptr_t)f->v & 15u) && !((uintptr_t)f->w & 15u);
+            if (can)
+            {
+                if (buoy) if (int e2 = mhh_thermo_dry_buoyancy_tend(g, p->buoyancy, f->wt, f->s[p->th_for_N2], p->threfh, p->grav, stream)) return e2;
+                const int m = mhh_rhs44_march(g, fq, stream);
+                if (m < 0) return -m;
+                MHH_REQUIRE(m == 1, "internal: rhs44 march declined a layout it was probed for");
+                for (int n=0; n<f->nscalars; ++n)
+                {
+                    if (int e2 = mhh_advec_s(g, MHH_ADVEC_4, f->st[n], f->s[n], f->u, f->v, f->w, f->rhoref, f->rhorefh, stream)) return e2;
+                    if (int e2 = mhh_diff_c(g, 4, f->st[n], f->s[n], f->svisc[n], stream)) return e2;
+                }
+                return MHH_OK;
+            }
+        }
 #define CALL(TF) [&]{ Rhs44Op<TF> op{make_grid<TF>(g), make_fields<TF>(f, p)}; return launch_interior(st, op.g, g->kstart, g->kend, op); }()
         return MHH_DISPATCH(g, CALL);
 #undef CALL

@@ -335,6 +335,34 @@ def test_exec_viscosity(be, sm, neutral, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_rhs44_marching_form_equals_cell_form(be, dtype):
+    """k_march4.hip (LDS planes + register columns, the view-generic arithmetic of cell_ops.h) against the one-thread-per-cell
+    Rhs44Op: same bits on tiles cut by the domain edge, several k-chunks, 2-D runs, with a scalar and folded buoyancy."""
+    shapes = [(70, 10, 12), (16, 12, 70), (18, 1, 8)] if dtype == np.float64 else [(74, 10, 12), (18, 9, 8), (16, 12, 10)]
+    for shape in shapes:
+        g = cm.grid_4th(*shape, dtype=dtype)
+        c = cm.Case(g, nscalars=1)
+        threfh = (300. + 0.37*np.arange(g.kcells)).astype(dtype)
+        out = {}
+        for impl in ("march", "cell"):
+            d = B.DevCase(be, c); f = d.fields(); dth = be.arr(threfh)
+            p = capi.MhhDiffParams(); p.buoyancy = 4; p.th_for_N2 = 0; p.threfh = be.ptr(dth).value; p.grav = 9.81
+            os.environ["MHH_RHS44_IMPL"] = impl
+            try:
+                n0 = be.lib.mhh_stat_rhs44_march_launches()
+                B.ok(be, be.lib.mhh_rhs_exec(d.G, cm.ADVEC_4, cm.DIFF_4, C.byref(f), C.byref(p), be.stream))
+                ran = be.lib.mhh_stat_rhs44_march_launches() - n0
+            finally:
+                del os.environ["MHH_RHS44_IMPL"]
+            out[impl] = [be.host(x) for x in (d.ut, d.vt, d.wt, d.st[0])]
+            aligned = g.icells % (2 if dtype == np.float64 else 4) == 0 and (dtype == np.float64 or g.igc == 3 and False)
+            if dtype == np.float64:
+                assert ran == (1 if impl == "march" else 0), (impl, shape, ran)
+        for a, b, nm in zip(out["march"], out["cell"], ("ut", "vt", "wt", "st")):
+            assert same(a, b), (shape, nm, cm.ulp_diff(a, b))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("sm,neutral", [(1, 0), (0, 0), (1, 1)])
 def test_exec_viscosity_marching_form_equals_cell_form(be, sm, neutral, dtype):
     """k_visc.hip (LDS planes, carried vertical-shear terms) against the one-thread-per-cell ViscosityOp: the same bits,
