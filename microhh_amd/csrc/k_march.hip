@@ -82,13 +82,17 @@ template<class TF> struct MarchFields
 //              barrier per level; rings one slot deeper so that the copy of the next plane can run under the whole
 //              compute phase). Needs 16-byte aligned rows: icells % (16/sizeof(TF)) == 0 and 16-byte aligned fields.
 // DMA = false: planes are staged through registers (prefetch, two barriers per level): any alignment.
-template<class TF, int NJ, bool HAS_S, bool DMA>
+// PB = 16 : LDS-DMA in 16-byte pieces (rows 16-byte aligned); PB = 4: LDS-DMA in 4-byte pieces (global_load_lds_dword):
+//           any layout, four times the copy instructions; PB = 0: register-staged.
+template<class TF, int NJ, bool HAS_S, int PB>
 __global__ void __launch_bounds__(64*NJ, MHH_MARCH_OCC) rhs25_march_kernel(const GridDev<TF> g, const MarchFields<TF> f, const MarchTiling mt)
 {
+    constexpr bool DMA = (PB != 0);
     constexpr int VEC = 16 / (int)sizeof(TF);                       // elements per 16-byte DMA piece
-    constexpr int TI = DMA ? ((70 + VEC-1)/VEC)*VEC : 70;           // u,v,w,s tile: x from i0-3
-    constexpr int EX = DMA ? VEC : 1;                               // evisc tile: x from i0-EX (aligned for DMA)
-    constexpr int TE = DMA ? ((64 + EX + 1 + VEC-1)/VEC)*VEC : 66;
+    constexpr int AL = (PB == 16) ? VEC : 1;                        // granularity of tile widths / origins in elements
+    constexpr int TI = ((70 + AL-1)/AL)*AL;                         // u,v,w,s tile: x from i0-3
+    constexpr int EX = (PB == 16) ? VEC : 1;                        // evisc tile: x from i0-EX (aligned for 16-byte DMA)
+    constexpr int TE = ((64 + EX + 1 + AL-1)/AL)*AL;
     constexpr int TJ = NJ + 6, TJE = NJ + 2, NT = 64*NJ;
     constexpr int NTILE = TI*TJ, NETILE = TE*TJE;
     constexpr int RU = DMA ? 3 : 2, RW = DMA ? 3 : 2, RE = DMA ? 4 : 3, RS = DMA ? 2 : 1;
@@ -115,30 +119,31 @@ __global__ void __launch_bounds__(64*NJ, MHH_MARCH_OCC) rhs25_march_kernel(const
     const int l = (ty+3)*TI + (tx+3), le = (ty+1)*TE + (tx+EX);
     auto slot = [](int p, int r) { return (p + 12) % r; };            // 12 is a multiple of every ring depth
 
-    // ---- tile movers. A tile is walked in pieces of PV elements: e = tid + n*NT; piece -> (row, first column) ------
-    constexpr int PV = DMA ? VEC : 1;
-    constexpr int PPR = TI / PV, PPRE = TE / PV;                      // pieces per tile row
+    // ---- tile movers. A tile is walked in pieces of PW 32-bit words: e = tid + n*NT; piece -> (row, first word) --------
+    constexpr int EW = (int)sizeof(TF) / 4;                           // words per element
+    constexpr int PW = DMA ? PB/4 : EW;                               // words per piece (staged: one element)
+    constexpr int PPR = TI*EW / PW, PPRE = TE*EW / PW;                // pieces per tile row
     constexpr int NP = PPR*TJ, NPE = PPRE*TJE;
     constexpr int NLD = (NP + NT - 1) / NT, NLDE = (NPE + NT - 1) / NT;
-    int off[NLD], offe[NLDE];
+    int off[NLD], offe[NLDE];                                         // word offsets from the start of a plane
     bool okt[NLD], oke[NLDE];
 #pragma unroll
     for (int n=0; n<NLD; ++n)
     {
         const int e = tid + n*NT;
-        const int tj = e / PPR, ti = (e - tj*PPR)*PV;
-        const int gi = i0 - 3 + ti, gj = j0 - 3 + tj;
-        okt[n] = (e < NP) && (gi + PV <= g.icells) && (gj < g.jcells);
-        off[n] = okt[n] ? gi + gj*jj : 0;
+        const int tj = e / PPR, tw = (e - tj*PPR)*PW;
+        const int gw = (i0 - 3)*EW + tw, gj = j0 - 3 + tj;
+        okt[n] = (e < NP) && (gw + PW <= g.icells*EW) && (gj < g.jcells);
+        off[n] = okt[n] ? gw + gj*jj*EW : 0;
     }
 #pragma unroll
     for (int n=0; n<NLDE; ++n)
     {
         const int e = tid + n*NT;
-        const int tj = e / PPRE, ti = (e - tj*PPRE)*PV;
-        const int gi = i0 - EX + ti, gj = j0 - 1 + tj;
-        oke[n] = (e < NPE) && (gi + PV <= g.icells) && (gj < g.jcells);
-        offe[n] = oke[n] ? gi + gj*jj : 0;
+        const int tj = e / PPRE, tw = (e - tj*PPRE)*PW;
+        const int gw = (i0 - EX)*EW + tw, gj = j0 - 1 + tj;
+        oke[n] = (e < NPE) && (gw + PW <= g.icells*EW) && (gj < g.jcells);
+        offe[n] = oke[n] ? gw + gj*jj*EW : 0;
     }
     // register-staged movers
     auto ld_tile = [&](const TF* __restrict__ fld, int kp, TF (&r)[NLD])
@@ -146,7 +151,7 @@ __global__ void __launch_bounds__(64*NJ, MHH_MARCH_OCC) rhs25_march_kernel(const
         const bool kok = (kp >= 0) && (kp < g.kcells);
         const TF* __restrict__ pl = fld + (kok ? (size_t)kp*kk : 0);
 #pragma unroll
-        for (int n=0; n<NLD; ++n) r[n] = (kok && okt[n]) ? pl[off[n]] : TF(0);
+        for (int n=0; n<NLD; ++n) r[n] = (kok && okt[n]) ? pl[off[n]/EW] : TF(0);
     };
     auto st_tile = [&](TF* __restrict__ lds, const TF (&r)[NLD])
     {
@@ -158,30 +163,31 @@ __global__ void __launch_bounds__(64*NJ, MHH_MARCH_OCC) rhs25_march_kernel(const
         const bool kok = (kp >= 0) && (kp < g.kcells);
         const TF* __restrict__ pl = f.ev + (kok ? (size_t)kp*kk : 0);
 #pragma unroll
-        for (int n=0; n<NLDE; ++n) r[n] = (kok && oke[n]) ? pl[offe[n]] : TF(0);
+        for (int n=0; n<NLDE; ++n) r[n] = (kok && oke[n]) ? pl[offe[n]/EW] : TF(0);
     };
     auto st_etile = [&](TF* __restrict__ lds, const TF (&r)[NLDE])
     {
 #pragma unroll
         for (int n=0; n<NLDE; ++n) { const int e = tid + n*NT; if (n+1 < NLDE || e < NPE) lds[e] = r[n]; }
     };
-    // LDS-DMA movers: 16 bytes per lane straight into the ring slot; lanes outside the tile / the array sit out
+    // LDS-DMA movers: PB bytes per lane straight into the ring slot; lanes outside the tile / the array sit out
     const int wave_e0 = tid & ~63;                                    // first piece index of this wave within a sweep
+    auto dma_piece = [](const uint32_t* src, uint32_t* dst) { if constexpr (PB == 16) lds_dma16(src, dst); else lds_dma4(src, dst); };
     auto dma_tile = [&](const TF* __restrict__ fld, int kp, TF* __restrict__ lds)
     {
         if (kp < 0 || kp >= g.kcells) return;                         // wave-uniform
-        const TF* __restrict__ pl = fld + (size_t)kp*kk;
+        const uint32_t* __restrict__ pl = reinterpret_cast<const uint32_t*>(fld + (size_t)kp*kk);
 #pragma unroll
         for (int n=0; n<NLD; ++n)
-            if (okt[n]) lds_dma16(pl + off[n], lds + (size_t)(wave_e0 + n*NT)*PV);
+            if (okt[n]) dma_piece(pl + off[n], reinterpret_cast<uint32_t*>(lds) + (size_t)(wave_e0 + n*NT)*PW);
     };
     auto dma_etile = [&](int kp, TF* __restrict__ lds)
     {
         if (kp < 0 || kp >= g.kcells) return;
-        const TF* __restrict__ pl = f.ev + (size_t)kp*kk;
+        const uint32_t* __restrict__ pl = reinterpret_cast<const uint32_t*>(f.ev + (size_t)kp*kk);
 #pragma unroll
         for (int n=0; n<NLDE; ++n)
-            if (oke[n]) lds_dma16(pl + offe[n], lds + (size_t)(wave_e0 + n*NT)*PV);
+            if (oke[n]) dma_piece(pl + offe[n], reinterpret_cast<uint32_t*>(lds) + (size_t)(wave_e0 + n*NT)*PW);
     };
     auto colval = [&](const TF* __restrict__ fld, int kp) -> TF
     {
@@ -452,21 +458,18 @@ int march_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* 
 #endif
     const MarchTiling t = make_march_tiling(g, NJ, MHH_MARCH_KC);
     const unsigned nblocks = march_blocks(t);
-    // LDS-DMA needs 16-byte aligned plane rows; otherwise the register-staged variant runs (same arithmetic)
+    // 16-byte LDS-DMA needs 16-byte aligned plane rows; other layouts copy in 4-byte pieces (MHH_MARCH_DMA=4 forces that
+    // form, =0 the register-staged one; same arithmetic in all three)
     constexpr int VEC = 16 / (int)sizeof(TF);
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
-    static const bool no_dma = [] { const char* e = getenv("MHH_MARCH_DMA"); return e && !strcmp(e, "0"); }();
-    const bool dma = !no_dma && (g->icells % VEC == 0) && al16(f->u) && al16(f->v) && al16(f->w) && al16(f->evisc) && (!has_s || al16(f->s[0]));
-    if (dma)
-    {
-        if (has_s) hipLaunchKernelGGL((rhs25_march_kernel<TF, NJ, true, true>),  dim3(nblocks), dim3(64, NJ), 0, st, gd, mf, t);
-        else       hipLaunchKernelGGL((rhs25_march_kernel<TF, NJ, false, true>), dim3(nblocks), dim3(64, NJ), 0, st, gd, mf, t);
-    }
-    else
-    {
-        if (has_s) hipLaunchKernelGGL((rhs25_march_kernel<TF, NJ, true, false>),  dim3(nblocks), dim3(64, NJ), 0, st, gd, mf, t);
-        else       hipLaunchKernelGGL((rhs25_march_kernel<TF, NJ, false, false>), dim3(nblocks), dim3(64, NJ), 0, st, gd, mf, t);
-    }
+    const char* env = getenv("MHH_MARCH_DMA");
+    const bool aligned = (g->icells % VEC == 0) && al16(f->u) && al16(f->v) && al16(f->w) && al16(f->evisc) && (!has_s || al16(f->s[0]));
+    const int pb = (env && !strcmp(env, "0")) ? 0 : ((env && !strcmp(env, "4")) || !aligned) ? 4 : 16;
+#define MHH_LAUNCH_MARCH(PBV) do { \
+        if (has_s) hipLaunchKernelGGL((rhs25_march_kernel<TF, NJ, true, PBV>),  dim3(nblocks), dim3(64, NJ), 0, st, gd, mf, t); \
+        else       hipLaunchKernelGGL((rhs25_march_kernel<TF, NJ, false, PBV>), dim3(nblocks), dim3(64, NJ), 0, st, gd, mf, t); } while (0)
+    if (pb == 16) MHH_LAUNCH_MARCH(16); else if (pb == 4) MHH_LAUNCH_MARCH(4); else MHH_LAUNCH_MARCH(0);
+#undef MHH_LAUNCH_MARCH
     MHH_LAUNCH_CHECK();
     return MHH_OK;
 }

@@ -53,11 +53,11 @@ template<class TF> __device__ __forceinline__ void shift7(TF (&w)[7], TF nw)
 #define MHH_MARCH4_KC 64
 #endif
 
-template<class TF, int NJ>
+template<class TF, int NJ, int PB>
 __global__ void __launch_bounds__(64*NJ, MHH_MARCH4_OCC) rhs44_march_kernel(const GridDev<TF> g, const March4Fields<TF> f, const MarchTiling mt)
 {
-    constexpr int VEC = 16 / (int)sizeof(TF);
-    constexpr int TI = ((70 + VEC-1)/VEC)*VEC, TJ = NJ + 6, NT = 64*NJ, NTILE = TI*TJ;
+    constexpr int AL = (PB == 16) ? 16 / (int)sizeof(TF) : 1;
+    constexpr int TI = ((70 + AL-1)/AL)*AL, TJ = NJ + 6, NT = 64*NJ, NTILE = TI*TJ;
     constexpr int RUV = 4, RW = 5;
     __shared__ __attribute__((aligned(16))) TF U[RUV][NTILE];
     __shared__ __attribute__((aligned(16))) TF V[RUV][NTILE];
@@ -78,25 +78,12 @@ __global__ void __launch_bounds__(64*NJ, MHH_MARCH4_OCC) rhs44_march_kernel(cons
     auto su = [](int p) { return (p + 16) % RUV; };
     auto sw = [](int p) { return (p + 20) % RW; };
 
-    constexpr int PPR = TI / VEC, NP = PPR*TJ, NLD = (NP + NT - 1) / NT;
-    int off[NLD]; bool okt[NLD];
-#pragma unroll
-    for (int n=0; n<NLD; ++n)
-    {
-        const int e = tid + n*NT;
-        const int tj = e / PPR, ti = (e - tj*PPR)*VEC;
-        const int gi = i0 - 3 + ti, gj = j0 - 3 + tj;
-        okt[n] = (e < NP) && (gi + VEC <= g.icells) && (gj < g.jcells);
-        off[n] = okt[n] ? gi + gj*jj : 0;
-    }
-    const int wave_e0 = tid & ~63;
+    TileCopy<TF, PB, TI, TJ, NT> tc;
+    tc.init(tid, i0 - 3, j0 - 3, g.icells, g.jcells);
     auto dma_tile = [&](const TF* __restrict__ fld, int kp, TF* __restrict__ lds)
     {
         if (kp < 0 || kp >= g.kcells) return;                         // wave-uniform
-        const TF* __restrict__ pl = fld + (size_t)kp*kk;
-#pragma unroll
-        for (int n=0; n<NLD; ++n)
-            if (okt[n]) lds_dma16(pl + off[n], lds + (size_t)(wave_e0 + n*NT)*VEC);
+        tc.copy(fld + (size_t)kp*kk, lds);
     };
     auto colval = [&](const TF* __restrict__ fld, int kp) -> TF { return (kp >= 0 && kp < g.kcells) ? fld[col + kp*kk] : TF(0); };
 
@@ -166,14 +153,15 @@ __global__ void __launch_bounds__(64*NJ, MHH_MARCH4_OCC) rhs44_march_kernel(cons
 }
 
 template<class TF>
-int march4_launch(const mhh_grid* g, const mhh_fields* f, hipStream_t st)
+int march4_launch(const mhh_grid* g, const mhh_fields* f, int pb, hipStream_t st)
 {
     constexpr int NJ = 4;
     March4Fields<TF> mf;
     mf.u = cp<TF>(f->u); mf.v = cp<TF>(f->v); mf.w = cp<TF>(f->w);
     mf.ut = mp<TF>(f->ut); mf.vt = mp<TF>(f->vt); mf.wt = mp<TF>(f->wt); mf.visc = TF(f->visc);
     const MarchTiling t = make_march_tiling(g, NJ, MHH_MARCH4_KC);
-    hipLaunchKernelGGL((rhs44_march_kernel<TF, NJ>), dim3(march_blocks(t)), dim3(64, NJ), 0, st, make_grid<TF>(g), mf, t);
+    if (pb == 16) hipLaunchKernelGGL((rhs44_march_kernel<TF, NJ, 16>), dim3(march_blocks(t)), dim3(64, NJ), 0, st, make_grid<TF>(g), mf, t);
+    else          hipLaunchKernelGGL((rhs44_march_kernel<TF, NJ, 4>),  dim3(march_blocks(t)), dim3(64, NJ), 0, st, make_grid<TF>(g), mf, t);
     MHH_LAUNCH_CHECK();
     return MHH_OK;
 }
@@ -183,15 +171,16 @@ static unsigned long long g_rhs44_march_launches = 0;
 MHH_API unsigned long long mhh_stat_rhs44_march_launches(void) { return g_rhs44_march_launches; }
 
 // Entry used by mhh_rhs_exec for (advec_4, diff_4): u, v, w only (scalars take the per-field kernels). Returns 1 when the
-// marching kernel ran, 0 when the layout does not meet the LDS-DMA alignment rules, < 0 on error (-code).
+// marching kernel ran, 0 when it is switched off (MHH_RHS44_IMPL=cell), < 0 on error (-code).
 int mhh_rhs44_march(const mhh_grid* g, const mhh_fields* f, void* stream)
 {
     { const char* e = getenv("MHH_RHS44_IMPL"); if (e && !strcmp(e, "cell")) return 0; }
     const int vec = (g->dtype == MHH_F64) ? 2 : 4;
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
-    if (g->icells % vec != 0 || (g->igc - 3) % vec != 0 || g->igc < 3 || g->jgc < 3 || g->kgc < 3) return 0;
-    if (!al16(f->u) || !al16(f->v) || !al16(f->w)) return 0;
+    if (g->igc < 3 || g->jgc < 3 || g->kgc < 3) return 0;
+    // 16-byte pieces need 16-byte aligned rows and tile origin (i0 - 3 = igc - 3 + 64*bx); other layouts copy in 4-byte pieces
+    const int pb = (g->icells % vec == 0 && (g->igc - 3) % vec == 0 && al16(f->u) && al16(f->v) && al16(f->w)) ? 16 : 4;
     ++g_rhs44_march_launches;
-    const int rc = (g->dtype == MHH_F64) ? march4_launch<double>(g, f, as_stream(stream)) : march4_launch<float>(g, f, as_stream(stream));
+    const int rc = (g->dtype == MHH_F64) ? march4_launch<double>(g, f, pb, as_stream(stream)) : march4_launch<float>(g, f, pb, as_stream(stream));
     return rc == MHH_OK ? 1 : -rc;
 }

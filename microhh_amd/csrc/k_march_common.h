@@ -1,7 +1,9 @@
 // k_march_common.h -- tiling shared by the k-marching kernels (k_march.hip, k_visc.hip): 64 x NJ column tiles that walk
 // up in k over chunks of kc levels, dealt to the 8 XCDs so that tiles sharing halos run next to each other on one L2.
 #pragma once
+#include <cstdint>
 #include "k_common.h"
+#include <gfx950_prims.h>
 
 namespace mhh
 {
@@ -44,4 +46,43 @@ inline unsigned march_blocks(const MarchTiling& t)
     const int units = t.ns * t.nkc;
     return 8u * (unsigned)((units + 7)/8) * (unsigned)t.sr * t.nbx;
 }
+
+// LDS-DMA copy of one TI x TJ tile of a plane (origin gi0, gj0 in grid cells) into an LDS slot, in pieces of PB bytes per
+// lane: PB = 16 (global_load_lds_dwordx4; rows and origin 16-byte aligned) or PB = 4 (global_load_lds_dword; any layout,
+// four times the instructions). Piece e = tid + n*NT covers words [tw, tw+PW) of tile row tj; lanes whose piece falls
+// outside the tile or the array sit out. lds_dma16 / lds_dma4 come from <gfx950_prims.h> (included by the kernels).
+template<class TF, int PB, int TI, int TJ, int NT>
+struct TileCopy
+{
+    static constexpr int EW = (int)sizeof(TF) / 4, PW = PB / 4;
+    static constexpr int PPR = TI*EW / PW, NP = PPR*TJ, NLD = (NP + NT - 1) / NT;
+    static_assert(PB == 4 || PB == 16, "piece size");
+    static_assert((TI*EW) % PW == 0, "tile row must be a whole number of pieces");
+    int off[NLD]; bool ok[NLD]; int wave_e0;
+    __device__ __forceinline__ void init(int tid, int gi0, int gj0, int icells, int jcells)
+    {
+        wave_e0 = tid & ~63;
+#pragma unroll
+        for (int n=0; n<NLD; ++n)
+        {
+            const int e = tid + n*NT;
+            const int tj = e / PPR, tw = (e - tj*PPR)*PW;
+            const int gw = gi0*EW + tw, gj = gj0 + tj;
+            ok[n] = (e < NP) && (gw >= 0) && (gw + PW <= icells*EW) && (gj >= 0) && (gj < jcells);
+            off[n] = ok[n] ? gw + gj*icells*EW : 0;
+        }
+    }
+    __device__ __forceinline__ void copy(const TF* __restrict__ plane, TF* __restrict__ lds) const
+    {
+        const uint32_t* __restrict__ pl = reinterpret_cast<const uint32_t*>(plane);
+        uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(lds);
+#pragma unroll
+        for (int n=0; n<NLD; ++n)
+            if (ok[n])
+            {
+                if constexpr (PB == 16) lds_dma16(pl + off[n], dst + (size_t)(wave_e0 + n*NT)*PW);
+                else                    lds_dma4 (pl + off[n], dst + (size_t)(wave_e0 + n*NT)*PW);
+            }
+    }
+};
 }

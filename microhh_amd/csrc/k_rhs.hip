@@ -447,9 +447,7 @@ MHH_API int mhh_rhs_exec(const mhh_grid* g, int advec_scheme, int diff_scheme, c
             const bool buoy = p && p->buoyancy;
             // probe the layout first so that the buoyancy term is added exactly once, and before advection
             const char* e = getenv("MHH_RHS44_IMPL");
-            const int vec = (g->dtype == MHH_F64) ? 2 : 4;
-            const bool can = !(e && !strcmp(e, "cell")) && g->icells % vec == 0 && (g->igc - 3) % vec == 0
-                             && !((uintptr_t)f->u & 15u) && !((uintptr_t)f->v & 15u) && !((uintptr_t)f->w & 15u);
+            const bool can = !(e && !strcmp(e, "cell"));
             if (can)
             {
                 if (buoy) if (int e2 = mhh_thermo_dry_buoyancy_tend(g, p->buoyancy, f->wt, f->s[p->th_for_N2], p->threfh, p->grav, stream)) return e2;

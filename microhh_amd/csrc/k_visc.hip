@@ -32,10 +32,9 @@ template<class TF> struct ViscFields
 #ifndef MHH_VISC_KC
 #define MHH_VISC_KC 64
 #endif
-template<class TF, int NJ>
+template<class TF, int NJ, int PB>
 __global__ void __launch_bounds__(64*NJ, MHH_VISC_OCC) visc_march_kernel(const GridDev<TF> g, const ViscFields<TF> f, const MarchTiling mt)
 {
-    constexpr int VEC = 16 / (int)sizeof(TF);
     constexpr int TI = 72, TJ = NJ + 2, NT = 64*NJ, NTILE = TI*TJ;    // tile x from i0-ex (ex <= 4: 64 + ex + 1 <= 72)
     constexpr int R = 3;                                              // ring: planes k, k+1 and the copy in flight
     __shared__ __attribute__((aligned(16))) TF U[R][NTILE];
@@ -56,26 +55,12 @@ __global__ void __launch_bounds__(64*NJ, MHH_VISC_OCC) visc_march_kernel(const G
     const int l = (ty+1)*TI + (tx+f.ex);
     auto slot = [](int p) { return (p + 12) % R; };
 
-    // tile pieces of 16 bytes: e = tid + n*NT -> (row, first column)
-    constexpr int PPR = TI / VEC, NP = PPR*TJ, NLD = (NP + NT - 1) / NT;
-    int off[NLD]; bool okt[NLD];
-#pragma unroll
-    for (int n=0; n<NLD; ++n)
-    {
-        const int e = tid + n*NT;
-        const int tj = e / PPR, ti = (e - tj*PPR)*VEC;
-        const int gi = i0 - f.ex + ti, gj = j0 - 1 + tj;
-        okt[n] = (e < NP) && (gi + VEC <= g.icells) && (gj < g.jcells);
-        off[n] = okt[n] ? gi + gj*jj : 0;
-    }
-    const int wave_e0 = tid & ~63;
+    TileCopy<TF, PB, TI, TJ, NT> tc;
+    tc.init(tid, i0 - f.ex, j0 - 1, g.icells, g.jcells);
     auto dma_tile = [&](const TF* __restrict__ fld, int kp, TF* __restrict__ lds)
     {
         if (kp < 0 || kp >= g.kcells) return;                         // wave-uniform
-        const TF* __restrict__ pl = fld + (size_t)kp*kk;
-#pragma unroll
-        for (int n=0; n<NLD; ++n)
-            if (okt[n]) lds_dma16(pl + off[n], lds + (size_t)(wave_e0 + n*NT)*VEC);
+        tc.copy(fld + (size_t)kp*kk, lds);
     };
     auto colth = [&](int kp) -> TF { return (f.th && kp >= 0 && kp < g.kcells) ? f.th[col + kp*kk] : TF(0); };
 
@@ -167,7 +152,7 @@ __global__ void __launch_bounds__(64*NJ, MHH_VISC_OCC) visc_march_kernel(const G
 }
 
 template<class TF>
-int visc_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, const void* th, int ex, hipStream_t st)
+int visc_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, const void* th, int ex, int pb, hipStream_t st)
 {
     constexpr int NJ = 4;
     ViscFields<TF> vf;
@@ -176,7 +161,8 @@ int visc_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p
     vf.N2 = cp<TF>(p->N2); vf.th = cp<TF>(th); vf.thref = cp<TF>(p->thref); vf.mlen0 = cp<TF>(p->mlen0);
     vf.grav = TF(p->grav); vf.tPr = TF(p->tPr); vf.sm = p->surface_model; vf.neutral = p->neutral; vf.ex = ex;
     const MarchTiling t = make_march_tiling(g, NJ, MHH_VISC_KC);
-    hipLaunchKernelGGL((visc_march_kernel<TF, NJ>), dim3(march_blocks(t)), dim3(64, NJ), 0, st, make_grid<TF>(g), vf, t);
+    if (pb == 16) hipLaunchKernelGGL((visc_march_kernel<TF, NJ, 16>), dim3(march_blocks(t)), dim3(64, NJ), 0, st, make_grid<TF>(g), vf, t);
+    else          hipLaunchKernelGGL((visc_march_kernel<TF, NJ, 4>),  dim3(march_blocks(t)), dim3(64, NJ), 0, st, make_grid<TF>(g), vf, t);
     MHH_LAUNCH_CHECK();
     return MHH_OK;
 }
@@ -186,19 +172,23 @@ static unsigned long long g_visc_march_launches = 0;
 // diagnostics: how many times the marching form (as opposed to the one-thread-per-cell form) has been launched
 MHH_API unsigned long long mhh_stat_visc_march_launches(void) { return g_visc_march_launches; }
 
-// Entry used by mhh_diff_exec_viscosity (inputs validated there). Returns 1 when the marching kernel ran, 0 when the
-// layout does not meet the LDS-DMA alignment rules (the caller then takes the cell kernel), < 0 on error (-code).
+// Entry used by mhh_diff_exec_viscosity (inputs validated there). Returns 1 when the marching kernel ran, 0 when it is
+// switched off (MHH_VISC_IMPL=cell) or the grid has no ghost cells to read (the caller then takes the cell kernel),
+// < 0 on error (-code).
 int mhh_visc_march(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, const void* th, void* stream)
 {
     { const char* e = getenv("MHH_VISC_IMPL"); if (e && !strcmp(e, "cell")) return 0; }     // A/B switch, read per call
     const int vec = (g->dtype == MHH_F64) ? 2 : 4;
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
-    if (g->icells % vec != 0 || !al16(f->u) || !al16(f->v) || !al16(f->w)) return 0;
-    // tile x-origin i0 - ex with i0 = igc + 64*bx must sit on a 16-byte boundary and cover i-1: 1 <= ex <= igc, (igc - ex) % vec == 0
+    if (g->igc < 1 || g->jgc < 1 || g->kgc < 1) return 0;
+    // 16-byte pieces: tile x-origin i0 - ex (i0 = igc + 64*bx) on a 16-byte boundary, covering i-1: 1 <= ex <= igc,
+    // (igc - ex) % vec == 0; any other layout copies in 4-byte pieces with ex = 1
     int ex = 0;
-    for (int e = 1; e <= g->igc && e <= 4; ++e) if ((g->igc - e) % vec == 0) { ex = e; break; }
-    if (ex == 0 || g->jgc < 1 || g->kgc < 1) return 0;
+    if (g->icells % vec == 0 && al16(f->u) && al16(f->v) && al16(f->w))
+        for (int e = 1; e <= g->igc && e <= 4; ++e) if ((g->igc - e) % vec == 0) { ex = e; break; }
+    const int pb = ex ? 16 : 4;
+    if (!ex) ex = 1;
     ++g_visc_march_launches;
-    const int rc = (g->dtype == MHH_F64) ? visc_launch<double>(g, f, p, th, ex, as_stream(stream)) : visc_launch<float>(g, f, p, th, ex, as_stream(stream));
+    const int rc = (g->dtype == MHH_F64) ? visc_launch<double>(g, f, p, th, ex, pb, as_stream(stream)) : visc_launch<float>(g, f, p, th, ex, pb, as_stream(stream));
     return rc == MHH_OK ? 1 : -rc;
 }

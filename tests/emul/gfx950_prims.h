@@ -9,5 +9,10 @@ inline void lds_dma16(const void* gsrc, void* lds_wave_base)
     const unsigned lane = (threadIdx.x + threadIdx.y*blockDim.x + threadIdx.z*blockDim.x*blockDim.y) & 63u;
     std::memcpy(static_cast<char*>(lds_wave_base) + lane*16, gsrc, 16);
 }
+inline void lds_dma4(const void* gsrc, void* lds_wave_base)
+{
+    const unsigned lane = (threadIdx.x + threadIdx.y*blockDim.x + threadIdx.z*blockDim.x*blockDim.y) & 63u;
+    std::memcpy(static_cast<char*>(lds_wave_base) + lane*4, gsrc, 4);
+}
 inline void wait_vmem() {}
 }
