@@ -105,10 +105,14 @@ __global__ void __launch_bounds__(64*NJ, MHH_MARCH4_OCC) rhs44_march_kernel(cons
         return t;
     };
 
+    // the u and v results of level k are stored at the top of iteration k+1: the s_waitcnt vmcnt(0) in front of the
+    // end-of-level barrier also waits for stores, and stores issued right before it would expose their latency
+    TF ut_pending = 0, vt_pending = 0; int c_pending = -1;
     for (int k = kb; k < ke; ++k)
     {
         const bool more = (k + 1 < ke);
         if (more) dma_tile(f.w, k+3, W[sw(k+3)]);
+        if (c_pending >= 0) { f.ut[c_pending] = ut_pending; f.vt[c_pending] = vt_pending; c_pending = -1; }
         const TF nu = more ? colval(f.u, k+4) : TF(0), nv = more ? colval(f.v, k+4) : TF(0), nw = more ? colval(f.w, k+4) : TF(0);
 
         const MarchView<TF, TI> Uv{{U[su(k-2)]+l, U[su(k-1)]+l, U[su(k)]+l, U[su(k+1)]+l, nullptr}, uw};
@@ -138,10 +142,11 @@ __global__ void __launch_bounds__(64*NJ, MHH_MARCH4_OCC) rhs44_march_kernel(cons
             const TF gc4[4] = {g.dzhi4[k-1], g.dzhi4[k], g.dzhi4[k+1], g.dzhi4[k+2]};
             advec4_mom_v<0>(ad, Uv, Uv, Vv, Wv, bot, top, dxi, dyi, g.dzi4[k], dim3);
             diff4_v(df, Uv, bot, top, f.visc, g.dxidxi_d, g.dyidyi_d, gc4, g.dzi4[k], dim3);
-            f.ut[c] = both(f.ut[c], ad, df);
+            ut_pending = both(f.ut[c], ad, df);
             advec4_mom_v<1>(ad, Vv, Uv, Vv, Wv, bot, top, dxi, dyi, g.dzi4[k], dim3);
             diff4_v(df, Vv, bot, top, f.visc, g.dxidxi_d, g.dyidyi_d, gc4, g.dzi4[k], dim3);
-            f.vt[c] = both(f.vt[c], ad, df);
+            vt_pending = both(f.vt[c], ad, df);
+            c_pending = c;
         }
         if (more)
         {
@@ -150,6 +155,7 @@ __global__ void __launch_bounds__(64*NJ, MHH_MARCH4_OCC) rhs44_march_kernel(cons
             shift7(uw, nu); shift7(vw, nv); shift7(ww, nw);
         }
     }
+    if (c_pending >= 0) { f.ut[c_pending] = ut_pending; f.vt[c_pending] = vt_pending; }
 }
 
 template<class TF>
