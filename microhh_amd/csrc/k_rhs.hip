@@ -405,7 +405,7 @@ MHH_API int mhh_rhs_exec(const mhh_grid* g, int advec_scheme, int diff_scheme, c
         }
         // default: the k-marching LDS kernel (k_march.hip) for u, v, w and scalar 0; further scalars take the
         // per-field kernels. MHH_RHS25_IMPL=cell selects the one-thread-per-cell fused kernel (A/B measurements).
-        static const bool use_cell = [] { const char* e = getenv("MHH_RHS25_IMPL"); return e && !strcmp(e, "cell"); }();
+        const bool use_cell = [] { const char* e = getenv("MHH_RHS25_IMPL"); return e && !strcmp(e, "cell"); }();   // A/B switch, read per call
         bool any_lim = false;
         for (int n=0; n<f->nscalars; ++n) any_lim = any_lim || f->s_fluxlimit[n];
         if (!use_cell || any_lim)
