@@ -15,6 +15,7 @@
 // Accumulation order per tendency is the reference's: t += advec_horizontal; t += advec_vertical; t += diffusion.
 #include <cstdint>
 #include <cstdlib>
+#include <type_traits>
 #include "k_common.h"
 #include "k_march_common.h"
 #include <gfx950_prims.h>   // angle form: the CPU emulation build (tests/emul) overrides it by include path
@@ -237,8 +238,15 @@ __global__ void __launch_bounds__(64*NJ, MHH_MARCH_OCC) rhs25_march_kernel(const
 #ifdef MHH_MARCH_STAMPS
     unsigned long long stamp_acc[8] = {0,0,0,0,0,0,0,0}; unsigned long long stamp_t = clock64();
 #endif
-    for (int k = ks; k < ke; ++k)
+    // One level. FAST = an interior level of an updating iteration: every vertical face is 6th/5th order, no wall or
+    // surface-flux branch applies -- the face orders and the wall predicates become constants and their dispatch
+    // (a third of the loop's scalar / control instructions) disappears. Same arithmetic either way.
+    // RHO1 = rhoref and rhorefh are exactly 1 on every level this block touches (Boussinesq base state): 1*x and x/1 are x,
+    // bit for bit, so the density factors and divisions drop out of the instantiation instead of being tested per use.
+    auto level = [&](const int k, auto fast_tag, auto rho1_tag)
     {
+        constexpr bool FAST = decltype(fast_tag)::value, RHO1 = decltype(rho1_tag)::value;
+        auto R = [](TF r, TF x) { return RHO1 ? x : r*x; };
         STAMP(0);
         // ---- start moving the next level's planes: k+1 of u, v, s; k+2 of w, evisc; window value k+4 ---------------
         TF pu[NLD], pv[NLD], pw[NLD], ps[NLD], pe[NLDE];        // staging registers (unused, and removed, in the DMA variant)
@@ -268,19 +276,15 @@ __global__ void __launch_bounds__(64*NJ, MHH_MARCH_OCC) rhs25_march_kernel(const
         // per-level coefficients (wave-uniform)
         const TF rhkp = f.rhorefh[k+1], rhk = f.rhorefh[k], rk = f.rhoref[k];
         const TF dzi = g.dzi[k], dzhi = g.dzhi[k], dzhip = g.dzhi[k+1];
-        const bool rk1 = (rk == TF(1.)), rhk1 = (rhk == TF(1.));
-#ifdef MHH_HACK_ORDER6      // timing experiment only (wrong near the walls): no order dispatch
-        constexpr int otc = 6, obc = 6, otw = 6, obw = 6; const bool wlev = true;
-#else
-        const int otc = order_face_c(k+1, g.kstart, g.kend);
-        const int obc = order_face_c(k, g.kstart, g.kend);
-        const bool wlev = (k >= g.kstart);                       // the w equation's "faces" are cell centres kstart..kend-1
-        const int otw = wlev ? order_face_w(k, g.kstart, g.kend) : 0;
-        const int obw = (k-1 >= g.kstart) ? order_face_w(k-1, g.kstart, g.kend) : 0;
-#endif
+        const bool rk1 = RHO1 || (rk == TF(1.)), rhk1 = RHO1 || (rhk == TF(1.));
+        const int otc = FAST ? 6 : order_face_c(k+1, g.kstart, g.kend);
+        const int obc = FAST ? 6 : order_face_c(k, g.kstart, g.kend);
+        const bool wlev = FAST || (k >= g.kstart);               // the w equation's "faces" are cell centres kstart..kend-1
+        const int otw = FAST ? 6 : (wlev ? order_face_w(k, g.kstart, g.kend) : 0);
+        const int obw = FAST ? 6 : ((k-1 >= g.kstart) ? order_face_w(k-1, g.kstart, g.kend) : 0);
         // surface model: the lowest / highest level takes the prescribed flux instead of the resolved one
-        const bool fb = f.sm && (k == g.kstart), ft = f.sm && (k == g.kend-1);
-        const bool need_dtop = !(ft) && (k < g.kend-1 || !f.sm) && (k+1 <= g.kend);   // top diffusive flux of level k is used by k or k+1
+        const bool fb = !FAST && f.sm && (k == g.kstart), ft = !FAST && f.sm && (k == g.kend-1);
+        const bool need_dtop = FAST || (!(ft) && (k < g.kend-1 || !f.sm) && (k+1 <= g.kend));   // top diffusive flux of level k is used by k or k+1
 
         STAMP(1);
         // ---- top-face quantities of level k --------------------------------------------------------------------
@@ -289,43 +293,43 @@ __global__ void __launch_bounds__(64*NJ, MHH_MARCH_OCC) rhs25_march_kernel(const
         {
             const TF wtu = i2(wkp[-1], wkp[0]);
             const TF wtv = i2(wkp[-TI], wkp[0]);
-            Tu = rhkp * wtu * win_cen(uw, otc);
-            Tv = rhkp * wtv * win_cen(vw, otc);
-            if (otc >= 4) { Gu = rhkp * tabs(wtu) * win_upw(uw, otc); Gv = rhkp * tabs(wtv) * win_upw(vw, otc); }
+            Tu = R(rhkp, wtu) * win_cen(uw, otc);
+            Tv = R(rhkp, wtv) * win_cen(vw, otc);
+            if (otc >= 4) { Gu = R(rhkp, tabs(wtu)) * win_upw(uw, otc); Gv = R(rhkp, tabs(wtv)) * win_upw(vw, otc); }
             if (HAS_S)
             {
-                Ts = rhkp * ww[4] * win_cen(sw, otc);
-                if (otc >= 4) Gs = rhkp * tabs(ww[4]) * win_upw(sw, otc);
+                Ts = R(rhkp, ww[4]) * win_cen(sw, otc);
+                if (otc >= 4) Gs = R(rhkp, tabs(ww[4])) * win_upw(sw, otc);
             }
         }
         if (wlev)
         {
             const TF wtw = i2(ww[3], ww[4]);
-            Tw = rk * wtw * win_cen(ww, otw);
-            if (otw >= 4) Gw = rk * tabs(wtw) * win_upw(ww, otw);
+            Tw = R(rk, wtw) * win_cen(ww, otw);
+            if (otw >= 4) Gw = R(rk, tabs(wtw)) * win_upw(ww, otw);
         }
         TF Du = 0, Dv = 0, Dw = 0, Ds = 0;
         if (need_dtop)
         {
             const TF etu = TF(0.25)*(ek[-1] + ek[0] + ekp[-1] + ekp[0]) + visc;
-            Du = rhkp * etu*((uw[4]-uw[3])*dzhip + (wkp[0]-wkp[-1])*dxd);
+            Du = R(rhkp, etu)*((uw[4]-uw[3])*dzhip + (wkp[0]-wkp[-1])*dxd);
             const TF etv = TF(0.25)*(ek[-TE] + ek[0] + ekp[-TE] + ekp[0]) + visc;
-            Dv = rhkp * etv*((vw[4]-vw[3])*dzhip + (wkp[0]-wkp[-TI])*dyd);
+            Dv = R(rhkp, etv)*((vw[4]-vw[3])*dzhip + (wkp[0]-wkp[-TI])*dyd);
             if (HAS_S)
             {
                 const TF ets = TF(0.5)*(ek[0]+ekp[0])/f.tPr + f.svisc;
-                Ds = rhkp * ets*(sw[4]-sw[3])*dzhip;
+                Ds = R(rhkp, ets)*(sw[4]-sw[3])*dzhip;
             }
         }
         if (wlev)
         {
             const TF etw = ek[0] + visc;
-            Dw = rk * etw*(ww[4]-ww[3])*dzi;
+            Dw = R(rk, etw)*(ww[4]-ww[3])*dzi;
         }
 
         STAMP(2);
         // ---- update the tendencies of level k ----------------------------------------------------------------
-        if (k >= kb && active)
+        if ((FAST || k >= kb) && active)
         {
             const int c = col + k*kk;
             {   // u
@@ -366,7 +370,7 @@ __global__ void __launch_bounds__(64*NJ, MHH_MARCH_OCC) rhs25_march_kernel(const
                 t += hor + ver;
                 f.vt[c] = t;
             }
-            if (k > g.kstart)
+            if (FAST || k > g.kstart)
             {   // w
                 const TF ue = i2(ukm[1], uk[1]), uwf = i2(ukm[0], uk[0]);
                 const TF vn = i2(vkm[TI], vk[TI]), vs = i2(vkm[0], vk[0]);
@@ -428,6 +432,22 @@ __global__ void __launch_bounds__(64*NJ, MHH_MARCH_OCC) rhs25_march_kernel(const
             }
             shift(uw, nu); shift(vw, nv); shift(ww, nw); shift(sw, ns);
         }
+    };
+    bool rho_one = true;                                           // wave-uniform: scalar loads of the chunk's base state
+    for (int k = ks; k <= ke; ++k) rho_one = rho_one && (f.rhoref[k] == TF(1.)) && (f.rhorefh[k] == TF(1.));
+#ifdef MHH_MARCH_NO_RHO1   // A/B builds only
+    rho_one = false;
+#endif
+    for (int k = ks; k < ke; ++k)
+    {
+        // interior level of an updating iteration: faces k and k+1 of the centred fields and the w "faces" k-1, k all 6th order
+#ifdef MHH_MARCH_NO_FAST    // A/B builds only
+        const bool fast = false;
+#else
+        const bool fast = (k >= kb) && (k >= g.kstart+3) && (k <= g.kend-4);
+#endif
+        if (rho_one) { if (fast) level(k, std::true_type{}, std::true_type{});  else level(k, std::false_type{}, std::true_type{}); }
+        else         { if (fast) level(k, std::true_type{}, std::false_type{}); else level(k, std::false_type{}, std::false_type{}); }
     }
 #ifdef MHH_MARCH_STAMPS
     if ((threadIdx.x & 63) == 0) for (int n=0; n<8; ++n) atomicAdd(&g_march_stamps[n], stamp_acc[n]);
