@@ -77,7 +77,10 @@ template<class TF> struct MarchFields
 };
 
 #ifndef MHH_MARCH_OCC
-#define MHH_MARCH_OCC 2
+#define MHH_MARCH_OCC 2           // fp64: 213-237 VGPRs, 74.6 KB LDS -> two blocks per CU
+#endif
+#ifndef MHH_MARCH_OCC_F32
+#define MHH_MARCH_OCC_F32 4       // fp32: half the registers and LDS -> four waves per SIMD (gabls1 1024x1024x256: 8.5 -> 7.9 ms)
 #endif
 // DMA = true : planes travel global -> LDS with global_load_lds_dwordx4 (no staging registers, no ds_write, one
 //              barrier per level; rings one slot deeper so that the copy of the next plane can run under the whole
@@ -86,7 +89,7 @@ template<class TF> struct MarchFields
 // PB = 16 : LDS-DMA in 16-byte pieces (rows 16-byte aligned); PB = 4: LDS-DMA in 4-byte pieces (global_load_lds_dword):
 //           any layout, four times the copy instructions; PB = 0: register-staged.
 template<class TF, int NJ, bool HAS_S, int PB>
-__global__ void __launch_bounds__(64*NJ, MHH_MARCH_OCC) rhs25_march_kernel(const GridDev<TF> g, const MarchFields<TF> f, const MarchTiling mt)
+__global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : MHH_MARCH_OCC)) rhs25_march_kernel(const GridDev<TF> g, const MarchFields<TF> f, const MarchTiling mt)
 {
     constexpr bool DMA = (PB != 0);
     constexpr int VEC = 16 / (int)sizeof(TF);                       // elements per 16-byte DMA piece
@@ -446,8 +449,10 @@ __global__ void __launch_bounds__(64*NJ, MHH_MARCH_OCC) rhs25_march_kernel(const
 #else
         const bool fast = (k >= kb) && (k >= g.kstart+3) && (k <= g.kend-4);
 #endif
-        if (rho_one) { if (fast) level(k, std::true_type{}, std::true_type{});  else level(k, std::false_type{}, std::true_type{}); }
-        else         { if (fast) level(k, std::true_type{}, std::false_type{}); else level(k, std::false_type{}, std::false_type{}); }
+        if constexpr (sizeof(TF) == 4)
+            level(k, std::false_type{}, std::false_type{});       // fp32: one body (127 VGPRs, 3-4 waves per SIMD); four bodies cost it a wave
+        else if (rho_one) { if (fast) level(k, std::true_type{}, std::true_type{});  else level(k, std::false_type{}, std::true_type{}); }
+        else              { if (fast) level(k, std::true_type{}, std::false_type{}); else level(k, std::false_type{}, std::false_type{}); }
     }
 #ifdef MHH_MARCH_STAMPS
     if ((threadIdx.x & 63) == 0) for (int n=0; n<8; ++n) atomicAdd(&g_march_stamps[n], stamp_acc[n]);
