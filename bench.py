@@ -169,9 +169,9 @@ def main():
     }
     if args.workload == "drycblles512" and world == 1 and not args.unfused:
         # HBM bytes per launch of this kernel on this workload from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and
-        # WRITE_SIZE in separate runs, FETCH_SIZE doubled for gfx950): profiles/r1c_march_kernel_pmc.md
-        out["roofline"]["traffic"] = (7.26e6 * 2 + 4.26e6) * 1024
-        out["roofline"]["traffic_source"] = "profiles/r1c_march_kernel_pmc.md"
+        # WRITE_SIZE in separate runs, FETCH_SIZE doubled for gfx950): profiles/r1e_kernels_pmc.md
+        out["roofline"]["traffic"] = (7.295e6 * 2 + 4.265e6) * 1024
+        out["roofline"]["traffic_source"] = "profiles/r1e_kernels_pmc.md"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline("drycblles" if case == "gabls1" else case)
     hp.close()
