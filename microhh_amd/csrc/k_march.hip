@@ -10,9 +10,13 @@
 //   * vertical face fluxes (advective centred/upwind parts and the Smagorinsky stress) are computed once, on the
 //     top face, and carried to the next level as its bottom face -- identical operands, identical rounding, so
 //     the result is still bit-identical to the reference CPU path (src/advec_2i5.cxx, src/diff_smag2.cxx);
-//   * the next plane is prefetched into registers while the current one is being computed (loads in flight
-//     across the whole compute phase), then written to the LDS ring between two barriers.
+//   * the next plane travels global -> LDS by LDS-DMA (16-byte pieces on aligned rows, 4-byte pieces on any other layout)
+//     into a spare ring slot while the current level is being computed: one barrier per level; a register-staged copy
+//     form (two barriers) remains selectable for A/B runs (MHH_MARCH_DMA=0);
+//   * fp64: the level body exists in four instantiations (interior level or not, base-state density exactly 1 or not),
+//     so that on the hot path the face orders, wall predicates and density factors are compile-time constants.
 // Accumulation order per tendency is the reference's: t += advec_horizontal; t += advec_vertical; t += diffusion.
+// Measurements and the experiments that did not pay: profiles/r1c_march_kernel_pmc.md, profiles/r1e_kernels_pmc.md.
 #include <cstdint>
 #include <cstdlib>
 #include <type_traits>
