@@ -335,6 +335,26 @@ def test_exec_viscosity(be, sm, neutral, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_fused_rhs_on_minimal_and_ragged_grids(be, dtype):
+    """Smallest legal vertical extent (every level is wall-adjacent: no interior fast path), tiles narrower than a wave,
+    a single row, and extents that are not multiples of the 64 x 4 tile: fused passes against the oracle's operator sequence."""
+    cases = [(cm.ADVEC_2I5, cm.DIFF_SMAG2, 1, [(8, 6, 6), (5, 3, 7), (66, 5, 9), (130, 3, 6)]),
+             (cm.ADVEC_4, cm.DIFF_4, 0, [(8, 6, 6), (6, 4, 5), (66, 5, 9)]),
+             (cm.ADVEC_2, cm.DIFF_2, 0, [(4, 3, 2), (66, 5, 3)])]
+    for adv, dif, sm, shapes in cases:
+        for shape in shapes:
+            g = cm.grid_4th(*shape, dtype=dtype) if adv == cm.ADVEC_4 else cm.grid_2nd(*shape, gc=((3, 3, 1) if adv == cm.ADVEC_2I5 else (1, 1, 1)), dtype=dtype)
+            c = cm.Case(g, nscalars=1)
+            want = _oracle_rhs(c, adv, dif, sm)
+            p = capi.MhhDiffParams(); p.cs = 0.23; p.tPr = 1./3.; p.surface_model = sm
+            d = B.DevCase(be, c); f = d.fields()
+            B.ok(be, be.lib.mhh_rhs_exec(d.G, adv, dif, C.byref(f), C.byref(p), be.stream))
+            got = (be.host(d.ut), be.host(d.vt), be.host(d.wt), be.host(d.st[0]))
+            for a, b, nm in zip(got, want[:3] + (want[3][0],), ("ut", "vt", "wt", "st")):
+                assert same(a, b), (adv, shape, nm, cm.ulp_diff(a, b))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_rhs25_march_copy_forms_agree(be, dtype):
     """The three plane-copy forms of k_march.hip (16-byte LDS-DMA, 4-byte LDS-DMA, register-staged) and the cell kernel
     give the same bits; layouts that are not 16-byte aligned take the 4-byte form by themselves."""
