@@ -201,6 +201,10 @@ typedef struct mhh_diff_params
     int    evisc_ghost_rows;
 } mhh_diff_params;
 int mhh_diff_exec_viscosity(const mhh_grid* g, int scheme, const mhh_fields* f, const mhh_diff_params* p, void* stream);
+/* exec_viscosity over the rows [j0, j1) of [jstart-1, jend+1) only (the wall mirror and the east-west wrap still cover
+ * all rows): lets the slab driver evaluate the rows that need no north-south halo while the halos travel. */
+int mhh_diff_exec_viscosity_rows(const mhh_grid* g, int scheme, const mhh_fields* f, const mhh_diff_params* p,
+                                 int j0, int j1, void* stream);
 /* diagnostic: launches of the k-marching form of exec_viscosity so far (it needs 16-byte aligned rows; other layouts
  * take the one-thread-per-cell kernel, same bits) */
 unsigned long long mhh_stat_visc_march_launches(void);
@@ -218,6 +222,11 @@ int mhh_thermo_dry_buoyancy_tend(const mhh_grid* g, int order, void* wt, const v
  * and one read-modify-write of every tendency. Supported pairs: (2,2) (25,22) (4,4).    */
 int mhh_rhs_exec(const mhh_grid* g, int advec_scheme, int diff_scheme, const mhh_fields* f,
                  const mhh_diff_params* p, void* stream);
+
+/* the (advec_2i5, diff_smag2) pass over the rows [j0, j1) of the interior only; u, v, w and at most one (unlimited)
+ * scalar; same bits as the whole-slab call on those rows */
+int mhh_rhs_exec_rows(const mhh_grid* g, int advec_scheme, int diff_scheme, const mhh_fields* f,
+                      const mhh_diff_params* p, int j0, int j1, void* stream);
 
 /* ---- Pressure ----------------------------------------------------------------------------
  * Plan object = Pres_2 / Pres_4 private state: bmati/bmatj, a/c (m1..m7), rocFFT plans,

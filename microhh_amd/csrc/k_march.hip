@@ -116,12 +116,12 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
     if (!decode_march(mt, blockIdx.x, bx, by, kcn)) return;        // whole block leaves together: no barrier hazard
     const int jj = g.icells, kk = g.ijcells;
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty*64 + tx;
-    const int i0 = g.istart + bx*64, j0 = g.jstart + by*NJ;
+    const int i0 = g.istart + bx*64, j0 = mt.jbase + by*NJ;
     const int kb = g.kstart + kcn*mt.kc;
     const int ke = (kb + mt.kc < g.kend) ? kb + mt.kc : g.kend;
     const int i = i0 + tx, j = j0 + ty;
-    const bool active = (i < g.iend) && (j < g.jend);
-    const int ci = (i < g.iend) ? i : g.iend-1, cj = (j < g.jend) ? j : g.jend-1;   // clamped column for the window loads
+    const bool active = (i < g.iend) && (j < mt.jlim);
+    const int ci = (i < g.iend) ? i : g.iend-1, cj = (j < mt.jlim) ? j : mt.jlim-1;   // clamped column for the window loads
     const int col = ci + cj*jj;
     const int ij = col;
     const int l = (ty+3)*TI + (tx+3), le = (ty+1)*TE + (tx+EX);
@@ -464,7 +464,7 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
 }
 
 template<class TF>
-int march_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, hipStream_t st)
+int march_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, int j0, int j1, hipStream_t st)
 {
 #ifndef MHH_MARCH_NJ
 #define MHH_MARCH_NJ 4
@@ -485,7 +485,9 @@ int march_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* 
 #ifndef MHH_MARCH_KC
 #define MHH_MARCH_KC 128
 #endif
-    const MarchTiling t = make_march_tiling(g, NJ, MHH_MARCH_KC);
+    // a strip of a few rows (mhh_rhs_exec_rows on the edge rows) takes short k-chunks: enough blocks to fill the GPU
+    const int kc = (j0 >= 0 && (j1 - j0) * 4 <= g->jmax) ? 16 : MHH_MARCH_KC;
+    const MarchTiling t = make_march_tiling(g, NJ, kc, j0, j1);
     const unsigned nblocks = march_blocks(t);
     // 16-byte LDS-DMA needs 16-byte aligned plane rows; other layouts copy in 4-byte pieces (MHH_MARCH_DMA=4 forces that
     // form, =0 the register-staged one; same arithmetic in all three)
@@ -507,8 +509,14 @@ int march_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* 
 // entry used by mhh_rhs_exec for the (advec_2i5, diff_smag2) pair: u, v, w and scalar 0 (inputs validated by the caller)
 int mhh_rhs25_march(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, void* stream)
 {
-    if (g->dtype == MHH_F64) return march_launch<double>(g, f, p, as_stream(stream));
-    return march_launch<float>(g, f, p, as_stream(stream));
+    if (g->dtype == MHH_F64) return march_launch<double>(g, f, p, -1, -1, as_stream(stream));
+    return march_launch<float>(g, f, p, -1, -1, as_stream(stream));
+}
+// the same over the rows [j0, j1) only (interior rows while the halos travel, edge rows after: mhh_rhs_exec_rows)
+int mhh_rhs25_march_rows(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, int j0, int j1, void* stream)
+{
+    if (g->dtype == MHH_F64) return march_launch<double>(g, f, p, j0, j1, as_stream(stream));
+    return march_launch<float>(g, f, p, j0, j1, as_stream(stream));
 }
 
 #ifdef MHH_MARCH_STAMPS

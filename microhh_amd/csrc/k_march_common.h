@@ -7,7 +7,7 @@
 
 namespace mhh
 {
-struct MarchTiling { int nbx, nby, nkc, sr, ns, kc; };
+struct MarchTiling { int nbx, nby, nkc, sr, ns, kc, jbase, jlim; };   // rows [jbase, jlim) are worked, in tiles from jbase
 
 __device__ __forceinline__ bool decode_march(const MarchTiling& t, unsigned L, int& bx, int& by, int& kc)
 {
@@ -30,10 +30,11 @@ __device__ __forceinline__ bool decode_march(const MarchTiling& t, unsigned L, i
 
 // strips of sr tile rows; (strip, k-chunk) units are dealt round-robin to the XCDs; sr shrinks on thin slabs so that all
 // 8 XCDs get work
-inline MarchTiling make_march_tiling(const mhh_grid* g, int NJ, int kc)
+inline MarchTiling make_march_tiling(const mhh_grid* g, int NJ, int kc, int j0 = -1, int j1 = -1)
 {
     MarchTiling t;
-    t.nbx = (g->imax + 63)/64; t.nby = (g->jmax + NJ-1)/NJ;
+    t.jbase = (j0 < 0) ? g->jstart : j0; t.jlim = (j1 < 0) ? g->jend : j1;
+    t.nbx = (g->imax + 63)/64; t.nby = (t.jlim - t.jbase + NJ-1)/NJ;
     t.kc = kc; t.nkc = (g->kmax + t.kc - 1)/t.kc;
     t.sr = (MHH_STRIP_ROWS + NJ-1)/NJ;
     if (t.sr * 8 > t.nby * t.nkc) t.sr = (t.nby * t.nkc) / 8;

@@ -13,6 +13,7 @@ every kernel is the hand-written HIP behind the C ABI. Case recipes follow SURVE
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 
@@ -55,7 +56,7 @@ class HotPath:
     """Device-resident fields of ONE rank + the operator calls of one sub-step."""
 
     def __init__(self, case, itot, jtot, ktot, dtype=np.float64, device="cuda:0", seed=666, dt=1.0,
-                 lib=None, npy=1, rank=0, group=None, global_init=None, force_slab=False, slim_halos=True):
+                 lib=None, npy=1, rank=0, group=None, global_init=None, force_slab=False, slim_halos=True, overlap=False):
         import torch
         self.torch = torch
         self.lib = lib if lib is not None else capi.lib()
@@ -67,6 +68,11 @@ class HotPath:
         # slim_halos: exchange only what the next kernel reads across the slab edge (one row of vt and of p, one direction
         # each) and evaluate evisc on the two adjacent ghost rows locally instead of exchanging it
         self.slim = bool(slim_halos)
+        # overlap: work the rows that need no north-south halo while the prognostic halos travel on a second stream
+        # (halo_visc_rhs). Opt-in (argument or MHH_OVERLAP=1): the split costs ~0.2 ms of small edge launches per step and what
+        # it hides (~0.4 ms of xGMI time at 512^3 / 8) could not be measured on the one-GPU box of this round.
+        self.overlap = bool(overlap) or os.environ.get("MHH_OVERLAP", "0") == "1"
+        self._comm_stream = None
         self.device = torch.device(device)
         self.on_gpu = self.device.type == "cuda"
         if self.slab and cfg["pres"] != 2:
@@ -189,8 +195,13 @@ class HotPath:
         if not self.slab:
             self._ok(self.lib.mhh_boundary_cyclic_n(self.G, arr, len(tensors), EDGE_BOTH, self.stream))
             return
-        import torch.distributed as dist
         self._ok(self.lib.mhh_boundary_cyclic_n(self.G, arr, len(tensors), EDGE_EW, self.stream))
+        self._exchange_ns(tensors, rows_south, rows_north)
+
+    def _exchange_ns(self, tensors, rows_south=None, rows_north=None):
+        """North-south part of halo(): pack, ring exchange (or local swap on one rank), unpack -- on the current stream."""
+        import torch.distributed as dist
+        arr = self._ptrs(tensors)
         g, nf = self.grid, len(tensors)
         rs = g.jgc if rows_south is None else rows_south
         rn = g.jgc if rows_north is None else rows_north
@@ -236,6 +247,51 @@ class HotPath:
     def cyclic_prognostic(self):
         self.halo(self._prog)
 
+    # -- the north-south exchange of the prognostic fields hidden behind the rows that do not need it -------------------
+    @property
+    def can_overlap(self):
+        g = self.grid
+        return (self.slab and self.overlap and self.evisc_local_ghosts and self.cfg["advec"] == ADVEC_2I5 and self.cfg["diff"] == DIFF_SMAG2
+                and len(self.s) == 1 and g.jgc >= 3 and g.jmax >= 12)
+
+    def halo_visc_rhs(self, ev=None):
+        """cyclic_prognostic + exec_viscosity + rhs of a slab rank with the halo exchange of u, v, w, th (jgc rows of four
+        fields each way: the largest message of the step) travelling on a second stream while the rows that need no
+        north-south halo are worked: evisc on rows [jstart+1, jend-1), tendencies on rows [jstart+4, jend-4); then the
+        edge rows. Row-wise calls give the bits of the whole-slab calls (tests/test_slab_gloo.py)."""
+        g, lib, torch = self.grid, self.lib, self.torch
+        adv, dif = self.cfg["advec"], self.cfg["diff"]
+        F, P = C.byref(self.fields), C.byref(self.params)
+        self._ok(lib.mhh_boundary_cyclic_n(self.G, self._ptrs(self._prog), len(self._prog), EDGE_EW, self.stream))
+        if self.on_gpu:
+            main = torch.cuda.current_stream(self.device)
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream(self.device)
+                self._ev = [torch.cuda.Event(), torch.cuda.Event()]
+            self._ev[0].record(main)
+            self._comm_stream.wait_event(self._ev[0])
+            with torch.cuda.stream(self._comm_stream):
+                self._exchange_ns(self._prog)
+                self._ev[1].record(self._comm_stream)
+        else:
+            self._exchange_ns(self._prog)
+        ja, jb = g.jstart + 4, g.jend - 4
+        if ev is not None:
+            ev[2].record()
+        self._ok(lib.mhh_diff_exec_viscosity_rows(self.G, dif, F, P, g.jstart + 1, g.jend - 1, self.stream))
+        if ev is not None:
+            ev[0].record()
+        self._ok(lib.mhh_rhs_exec_rows(self.G, adv, dif, F, P, ja, jb, self.stream))
+        if ev is not None:
+            ev[1].record()
+        self.rhs_rows_timed = jb - ja
+        if self.on_gpu:
+            torch.cuda.current_stream(self.device).wait_event(self._ev[1])
+        self._ok(lib.mhh_diff_exec_viscosity_rows(self.G, dif, F, P, g.jstart - 1, g.jstart + 1, self.stream))
+        self._ok(lib.mhh_diff_exec_viscosity_rows(self.G, dif, F, P, g.jend - 1, g.jend + 1, self.stream))
+        self._ok(lib.mhh_rhs_exec_rows(self.G, adv, dif, F, P, g.jstart, ja, self.stream))
+        self._ok(lib.mhh_rhs_exec_rows(self.G, adv, dif, F, P, jb, g.jend, self.stream))
+
     # -- the operator calls -----------------------------------------------------------------------------------
     def exec_viscosity(self):
         self._ok(self.lib.mhh_diff_exec_viscosity(self.G, self.cfg["diff"], C.byref(self.fields), C.byref(self.params), self.stream))
@@ -278,9 +334,12 @@ class HotPath:
 
     def step(self):
         """One full RHS + pressure evaluation (the BASELINE metric's unit of work)."""
-        self.cyclic_prognostic()
-        self.exec_viscosity()
-        self.rhs()
+        if self.can_overlap:
+            self.halo_visc_rhs()
+        else:
+            self.cyclic_prognostic()
+            self.exec_viscosity()
+            self.rhs()
         self.pres()
 
     # -- reductions (local max, then MAX over ranks: Master::max, src/master_parallel.cxx:233-266) --------------

@@ -120,6 +120,15 @@ def test_slab_code_path_matches_single_rank_bits_at_256():
     it = (slice(g.kstart, g.kend), slice(g.jstart, g.jend), slice(g.istart, g.iend))
     for n in ("evisc", "ut", "vt", "wt"):
         assert torch.equal(getattr(a, n)[it], getattr(b, n)[it]), n
+    # the overlapped order: exchange on its own stream, interior rows meanwhile, edge rows after (fresh fields each time)
+    for _ in range(3):
+        c = _hp("drycblles", shape, global_init=gi, force_slab=True, overlap=True)
+        assert c.can_overlap
+        c.halo_visc_rhs(); c.sync()
+        for n in ("evisc", "ut", "vt", "wt"):
+            assert torch.equal(getattr(a, n)[it], getattr(c, n)[it]), ("overlapped", n)
+        assert torch.equal(a.st[0][it], c.st[0][it])
+        c.close()
     a.pres(); b.pres(); a.sync(); b.sync()
     for n in ("p", "ut", "vt", "wt"):
         x, y = getattr(a, n)[it], getattr(b, n)[it]

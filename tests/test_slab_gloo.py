@@ -25,11 +25,16 @@ def _interior(hp, t):
     return t[g.kstart:g.kend, g.jstart:g.jend, g.istart:g.iend].numpy().copy()
 
 
-def _run(hp, out):
-    hp.cyclic_prognostic()
-    hp.exec_viscosity()
+def _run(hp, out, overlapped=False):
+    if overlapped:
+        assert hp.can_overlap
+        hp.halo_visc_rhs()               # interior rows while the halos travel, then the edge rows
+    else:
+        hp.cyclic_prognostic()
+        hp.exec_viscosity()
     out["evisc"] = _interior(hp, hp.evisc)
-    hp.rhs()
+    if not overlapped:
+        hp.rhs()
     for n in ("ut", "vt", "wt"):
         out["rhs_" + n] = _interior(hp, getattr(hp, n))
     out["rhs_st"] = _interior(hp, hp.st[0])
@@ -46,10 +51,10 @@ def _worker(rank, world, port, tmp, slim):
     try:
         lib = B.get("emul").lib
         hp = HotPath("drycblles", *GRID, device="cpu", lib=lib, npy=world, rank=rank, global_init=synthetic_global("drycblles", *GRID),
-                     slim_halos=slim)
+                     slim_halos=slim, overlap=(slim and world == 2))
         assert hp.evisc_local_ghosts == slim
         out = {}
-        _run(hp, out)
+        _run(hp, out, overlapped=(slim and world == 2))
         np.savez(os.path.join(tmp, "rank%d.npz" % rank), **out)
         hp.close()
     finally:
