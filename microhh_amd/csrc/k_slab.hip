@@ -166,6 +166,7 @@ MHH_API void mhh_pres_slab_plan_destroy(mhh_pres_slab_plan* P)
     delete P;
 }
 
+static int slab_factor(mhh_pres_slab_plan* P);     // tdma_slab_factor_kernel launch, defined with the kernel
 MHH_API int mhh_pres_slab_plan_create(const mhh_grid* g, const void* host_dz, const void* host_dzhi, const void* host_rhoref, const void* host_rhorefh,
                                       mhh_pres_slab_plan** out)
 {
@@ -181,7 +182,7 @@ MHH_API int mhh_pres_slab_plan_create(const mhh_grid* g, const void* host_dz, co
                                   : slab_tables<float>(P, g, host_dz, host_dzhi, host_rhoref, host_rhorefh);
     const size_t nreal = (size_t)g->itot*g->jmax*g->ktot, nx = (size_t)P->nxh*g->jmax*g->ktot, ny = (size_t)P->nxb*g->jtot*g->ktot;
     auto alloc = [&](void** p, size_t bytes) { if (e) return; hipError_t h = hipMalloc(p, bytes); if (h != hipSuccess) { set_error("hipMalloc: %s", hipGetErrorString(h)); e = MHH_ENOMEM; } };
-    alloc(&P->packed, nreal*P->esz); alloc(&P->specx, nx*2*P->esz); alloc(&P->specy, ny*2*P->esz); alloc(&P->work, ny*P->esz);
+    alloc(&P->packed, nreal*P->esz); alloc(&P->specx, nx*2*P->esz); alloc(&P->specy, ny*2*P->esz); alloc(&P->work, 2*ny*P->esz);          // pivots w2 and eliminated upper diagonal w3 of every column, factored below
     if (!e)
     {
         rocfft_setup();
@@ -198,6 +199,7 @@ MHH_API int mhh_pres_slab_plan_create(const mhh_grid* g, const void* host_dz, co
             if (!e && rocfft_execution_info_set_work_buffer(P->info, P->wb, P->wbs) != rocfft_status_success) { set_error("FFT error: set_work_buffer"); e = MHH_EFFT; }
         }
     }
+    if (!e) e = slab_factor(P);
     if (e) { mhh_pres_slab_plan_destroy(P); return e; }
     *out = P;
     return MHH_OK;
@@ -273,60 +275,125 @@ __global__ void __launch_bounds__(256) xbuf_y_kernel(C2<TF>* __restrict__ specy,
     }
 }
 
-// Thomas algorithm on specy (src/pres_2.cxx:289-330 matrix, :202-263 tdma). One thread per (ky, re|im) COMPONENT of a
-// column: the matrix is real, so the two components are independent solves with the same pivots; splitting them
-// doubles the parallelism of a sweep that has only nxb*jtot columns per rank (33 x 512 at 512^3 on 8 GPUs), and the
-// lanes of a wave still read consecutive 8-byte words. The pivot recurrence does not depend on the right-hand
-// side, so the loads of the next levels are free to run ahead of it (unrolled by 4).
+// Thomas solve of the slab stage (src/pres_2.cxx:289-330 matrix, :202-263 tdma) on the rank's (x-block, all y) columns.
+// A rank has only nxb*jtot columns (33 x 512 at 512^3 on 8 GPUs: half a wave per SIMD), so the sweep is latency-bound
+// and organised for that:
+//   * the pivots w2 and the eliminated upper diagonal w3 depend on the grid and (kx, ky) only: computed ONCE at plan
+//     creation (tdma_slab_factor_kernel, the reference's recurrence) and kept, 2 x nxb*jtot*kmax values;
+//   * one thread per (ky, re|im) component -- twice the parallelism, lanes still read consecutive 8-byte words;
+//   * the right-hand side and pivots of the next 8 levels are loaded while the 8 current levels run through the
+//     recurrence (only a multiply-subtract and the division by the pivot are left on the dependent chain).
 template<class TF>
-__global__ void __launch_bounds__(128) tdma_slab_kernel(TF* __restrict__ p, TF* __restrict__ work3d,
-                                                        const TF* __restrict__ bmati, const TF* __restrict__ bmatj,
-                                                        const TF* __restrict__ a, const TF* __restrict__ c, const TF* __restrict__ dz, const TF* __restrict__ rho,
+__global__ void __launch_bounds__(64) tdma_slab_factor_kernel(TF* __restrict__ W2, TF* __restrict__ W3,
+                                                              const TF* __restrict__ bmati, const TF* __restrict__ bmatj,
+                                                              const TF* __restrict__ a, const TF* __restrict__ c, const TF* __restrict__ dz, const TF* __restrict__ rho,
+                                                              int nxh, int nxb, int kx0, int jtot, int kmax)
+{
+    const int ky = blockIdx.x*64 + threadIdx.x, kxl = blockIdx.y;
+    const int kx = kx0 + kxl;
+    if (ky >= jtot || kx >= nxh) return;
+    const size_t kk = (size_t)nxb*jtot, col = (size_t)kxl*jtot + ky;
+    const TF bm = bmati[kx] + bmatj[ky];
+    const bool mean = (kx == 0 && ky == 0);
+    TF w2;
+    {
+        const TF dz2 = dz[0]*dz[0];
+        TF b = dz2 * rho[0]*bm - (a[0]+c[0]);
+        b += a[0];
+        if (kmax == 1) { if (mean) b -= c[0]; else b += c[0]; }
+        w2 = b;
+        W2[col] = w2; W3[col] = TF(0);
+    }
+    for (int k=1; k<kmax; ++k)
+    {
+        const TF dz2 = dz[k]*dz[k];
+        TF b = dz2 * rho[k]*bm - (a[k]+c[k]);
+        if (k == kmax-1) { if (mean) b -= c[k]; else b += c[k]; }
+        const TF w3 = c[k-1] / w2;
+        w2 = b - a[k]*w3;
+        W2[col + (size_t)k*kk] = w2; W3[col + (size_t)k*kk] = w3;
+    }
+}
+template<class TF>
+__global__ void __launch_bounds__(128) tdma_slab_kernel(TF* __restrict__ p, const TF* __restrict__ W2, const TF* __restrict__ W3,
+                                                        const TF* __restrict__ a, const TF* __restrict__ dz,
                                                         int nxh, int nxb, int kx0, int jtot, int kmax)
 {
+    constexpr int U = 8;
     const int t = blockIdx.x*128 + threadIdx.x;           // 0 .. 2*jtot-1
     const int ky = t >> 1, comp = t & 1, kxl = blockIdx.y;
     const int kx = kx0 + kxl;                              // swapped indices: this rank owns a block of x modes, all y modes
     if (ky >= jtot || kx >= nxh) return;
     const size_t kk = (size_t)nxb*jtot, col = (size_t)kxl*jtot + ky;
     TF* __restrict__ q = p + 2*col + comp;                 // component stream, stride 2*kk per level
-    const TF bm = bmati[kx] + bmatj[ky];
-    const bool mean = (kx == 0 && ky == 0);
-    TF w2, pp;
+    const TF* __restrict__ w2 = W2 + col; const TF* __restrict__ w3 = W3 + col;
+    TF pp;
     {
-        const TF dz2 = dz[0]*dz[0];
-        TF b = dz2 * rho[0]*bm - (a[0]+c[0]);
-        b += a[0];
-        if (kmax == 1) { if (mean) b -= c[0]; else b += c[0]; }
-        TF v = dz2 * q[0];
-        w2 = b;
-        v /= w2;
+        TF v = dz[0]*dz[0] * q[0];
+        v /= w2[0];
         q[0] = v; pp = v;
     }
-#pragma unroll 4
-    for (int k=1; k<kmax; ++k)
+    // forward sweep, levels 1 .. kmax-1 in blocks of U with the next block's operands in flight
+    TF qc[U], wc[U];
+#pragma unroll
+    for (int u=0; u<U; ++u) { const int k = 1 + u; const bool ok = k < kmax; qc[u] = ok ? q[2*(size_t)k*kk] : TF(0); wc[u] = ok ? w2[(size_t)k*kk] : TF(1); }
+    for (int k0=1; k0<kmax; k0+=U)
     {
-        const size_t e = (size_t)k*kk;
-        const TF dz2 = dz[k]*dz[k];
-        TF b = dz2 * rho[k]*bm - (a[k]+c[k]);
-        if (k == kmax-1) { if (mean) b -= c[k]; else b += c[k]; }
-        TF v = dz2 * q[2*e];
-        const TF w3 = c[k-1] / w2;
-        work3d[col + e] = w3;          // both components store the same value: each later reads what it wrote itself
-        w2 = b - a[k]*w3;
-        v -= a[k]*pp;
-        v /= w2;
-        q[2*e] = v; pp = v;
+        TF qn[U], wn[U];
+#pragma unroll
+        for (int u=0; u<U; ++u) { const int k = k0 + U + u; const bool ok = k < kmax; qn[u] = ok ? q[2*(size_t)k*kk] : TF(0); wn[u] = ok ? w2[(size_t)k*kk] : TF(1); }
+#pragma unroll
+        for (int u=0; u<U; ++u)
+        {
+            const int k = k0 + u;
+            if (k < kmax)
+            {
+                TF v = dz[k]*dz[k] * qc[u];
+                v -= a[k]*pp;
+                v /= wc[u];
+                q[2*(size_t)k*kk] = v; pp = v;
+            }
+        }
+#pragma unroll
+        for (int u=0; u<U; ++u) { qc[u] = qn[u]; wc[u] = wn[u]; }
     }
-#pragma unroll 4
-    for (int k=kmax-2; k>=0; --k)
+    // backward sweep, levels kmax-2 .. 0
+#pragma unroll
+    for (int u=0; u<U; ++u) { const int k = kmax-2 - u; const bool ok = k >= 0; qc[u] = ok ? q[2*(size_t)k*kk] : TF(0); wc[u] = ok ? w3[(size_t)(k+1)*kk] : TF(0); }
+    for (int k0=kmax-2; k0>=0; k0-=U)
     {
-        const size_t e = (size_t)k*kk;
-        const TF w3 = work3d[col + e + kk];
-        TF v = q[2*e];
-        v -= w3*pp;
-        q[2*e] = v; pp = v;
+        TF qn[U], wn[U];
+#pragma unroll
+        for (int u=0; u<U; ++u) { const int k = k0 - U - u; const bool ok = k >= 0; qn[u] = ok ? q[2*(size_t)k*kk] : TF(0); wn[u] = ok ? w3[(size_t)(k+1)*kk] : TF(0); }
+#pragma unroll
+        for (int u=0; u<U; ++u)
+        {
+            const int k = k0 - u;
+            if (k >= 0)
+            {
+                TF v = qc[u];
+                v -= wc[u]*pp;
+                q[2*(size_t)k*kk] = v; pp = v;
+            }
+        }
+#pragma unroll
+        for (int u=0; u<U; ++u) { qc[u] = qn[u]; wc[u] = wn[u]; }
     }
+}
+
+static int slab_factor(mhh_pres_slab_plan* P)
+{
+    dim3 gf((P->jtot + 63)/64, P->nxb);
+    const size_t ny = (size_t)P->nxb*P->jtot*P->ktot;
+    if (P->dtype == MHH_F64)
+        hipLaunchKernelGGL(tdma_slab_factor_kernel<double>, gf, dim3(64), 0, 0, (double*)P->work, (double*)P->work + ny, cp<double>(P->bmati), cp<double>(P->bmatj),
+                           cp<double>(P->a), cp<double>(P->c), cp<double>(P->dz), cp<double>(P->rhoref), P->nxh, P->nxb, P->rank*P->nxb, P->jtot, P->ktot);
+    else
+        hipLaunchKernelGGL(tdma_slab_factor_kernel<float>, gf, dim3(64), 0, 0, (float*)P->work, (float*)P->work + ny, cp<float>(P->bmati), cp<float>(P->bmatj),
+                           cp<float>(P->a), cp<float>(P->c), cp<float>(P->dz), cp<float>(P->rhoref), P->nxh, P->nxb, P->rank*P->nxb, P->jtot, P->ktot);
+    hipError_t h = hipGetLastError(); if (h == hipSuccess) h = hipStreamSynchronize(0);
+    if (h != hipSuccess) { set_error("tdma_slab_factor: %s", hipGetErrorString(h)); return MHH_EHIP; }
+    return MHH_OK;
 }
 
 // packed real [k][jl][i] -> ghosted p: interior rows + x halo (wrap) + bottom ghost level; the y halo is the caller's exchange
@@ -382,8 +449,8 @@ MHH_API int mhh_pres_fwd_y_solve_bwd_y(mhh_pres_slab_plan* P, const mhh_grid* g,
         hipLaunchKernelGGL((xbuf_y_kernel<double, true>), gy, dim3(256), 0, st, (C2<double>*)P->specy, (C2<double>*)recvbuf, P->nxb, P->jmax, P->jtot, P->ktot);
         MHH_LAUNCH_CHECK();
         MHH_FFT_TRY(rocfft_execute(P->fy, io, nullptr, P->info));
-        hipLaunchKernelGGL(tdma_slab_kernel<double>, gs, dim3(128), 0, st, (double*)P->specy, (double*)P->work, cp<double>(P->bmati), cp<double>(P->bmatj),
-                           cp<double>(P->a), cp<double>(P->c), cp<double>(P->dz), cp<double>(P->rhoref), P->nxh, P->nxb, P->rank*P->nxb, P->jtot, P->ktot);
+        hipLaunchKernelGGL(tdma_slab_kernel<double>, gs, dim3(128), 0, st, (double*)P->specy, cp<double>(P->work), cp<double>(P->work) + (size_t)P->nxb*P->jtot*P->ktot,
+                           cp<double>(P->a), cp<double>(P->dz), P->nxh, P->nxb, P->rank*P->nxb, P->jtot, P->ktot);
         MHH_LAUNCH_CHECK();
         MHH_FFT_TRY(rocfft_execute(P->by, io, nullptr, P->info));
         hipLaunchKernelGGL((xbuf_y_kernel<double, false>), gy, dim3(256), 0, st, (C2<double>*)P->specy, (C2<double>*)sendbuf, P->nxb, P->jmax, P->jtot, P->ktot);
@@ -393,8 +460,8 @@ MHH_API int mhh_pres_fwd_y_solve_bwd_y(mhh_pres_slab_plan* P, const mhh_grid* g,
         hipLaunchKernelGGL((xbuf_y_kernel<float, true>), gy, dim3(256), 0, st, (C2<float>*)P->specy, (C2<float>*)recvbuf, P->nxb, P->jmax, P->jtot, P->ktot);
         MHH_LAUNCH_CHECK();
         MHH_FFT_TRY(rocfft_execute(P->fy, io, nullptr, P->info));
-        hipLaunchKernelGGL(tdma_slab_kernel<float>, gs, dim3(128), 0, st, (float*)P->specy, (float*)P->work, cp<float>(P->bmati), cp<float>(P->bmatj),
-                           cp<float>(P->a), cp<float>(P->c), cp<float>(P->dz), cp<float>(P->rhoref), P->nxh, P->nxb, P->rank*P->nxb, P->jtot, P->ktot);
+        hipLaunchKernelGGL(tdma_slab_kernel<float>, gs, dim3(128), 0, st, (float*)P->specy, cp<float>(P->work), cp<float>(P->work) + (size_t)P->nxb*P->jtot*P->ktot,
+                           cp<float>(P->a), cp<float>(P->dz), P->nxh, P->nxb, P->rank*P->nxb, P->jtot, P->ktot);
         MHH_LAUNCH_CHECK();
         MHH_FFT_TRY(rocfft_execute(P->by, io, nullptr, P->info));
         hipLaunchKernelGGL((xbuf_y_kernel<float, false>), gy, dim3(256), 0, st, (C2<float>*)P->specy, (C2<float>*)sendbuf, P->nxb, P->jmax, P->jtot, P->ktot);

@@ -12,16 +12,21 @@ lib = capi.lib()
 hp = HotPath("drycblles", n, n, n, npy=npy, rank=0, group=None, global_init=None) if False else None
 # build the rank-0 object without a process group: construct with npy ranks but never call the exchanges
 class NoComm(HotPath):
-    def halo(self, tensors):
+    def _exchange_ns(self, tensors, rows_south=None, rows_north=None):
         arr = self._ptrs(tensors)
-        self._ok(self.lib.mhh_boundary_cyclic_n(self.G, arr, len(tensors), 0, self.stream))
-        nf = len(tensors)
-        if nf not in self._halo:
-            m = int(self.lib.mhh_halo_buffer_elems(self.G, nf))
-            self._halo[nf] = [torch.zeros(m, device=self.device, dtype=self.td) for _ in range(4)]
-        s_south, s_north, r_south, r_north = self._halo[nf]
-        self._ok(self.lib.mhh_halo_pack_ns(self.G, arr, nf, s_south.data_ptr(), s_north.data_ptr(), self.stream))
-        self._ok(self.lib.mhh_halo_unpack_ns(self.G, arr, nf, s_north.data_ptr(), s_south.data_ptr(), self.stream))
+        g, nf = self.grid, len(tensors)
+        rs = g.jgc if rows_south is None else rows_south
+        rn = g.jgc if rows_north is None else rows_north
+        key = (nf, rs, rn)
+        if key not in self._halo:
+            per_row = nf * g.kcells * g.icells
+            mk = lambda rows: torch.zeros(max(1, rows * per_row), device=self.device, dtype=self.td)
+            self._halo[key] = [mk(rs), mk(rn), mk(rn), mk(rs)]
+        s_south, s_north, r_south, r_north = self._halo[key]
+        self._ok(self.lib.mhh_halo_pack_rows(self.G, arr, nf, rs, rn, s_south.data_ptr(), s_north.data_ptr(), self.stream))
+        self._ok(self.lib.mhh_halo_unpack_rows(self.G, arr, nf, rs, rn, r_south.data_ptr(), r_north.data_ptr(), self.stream))
+    def _halo2d(self, t):
+        pass
     def _transpose(self):
         pass
 hp = NoComm("drycblles", n, n, n, npy=npy, rank=0)
@@ -40,12 +45,12 @@ res = {
  "cyclic_prognostic(4 fields)": timeit(hp.cyclic_prognostic),
  "exec_viscosity+halo": timeit(hp.exec_viscosity),
  "rhs": timeit(hp.rhs),
- "halo(vt)": timeit(lambda: hp.halo([hp.vt])),
+ "halo(vt, 1 row south)": timeit(lambda: hp.halo([hp.vt], rows_south=1, rows_north=0)),
  "pres_input": timeit(lambda: lib.mhh_pres_input_packed(hp.G, 2, f, 1.0, packed, st)),
  "fwd_x_pack": timeit(lambda: lib.mhh_pres_fwd_x_pack(hp.plan, hp.G, packed, hp.xsend.data_ptr(), st)),
  "fwd_y_solve_bwd_y": timeit(lambda: lib.mhh_pres_fwd_y_solve_bwd_y(hp.plan, hp.G, hp.xrecv.data_ptr(), hp.xsend.data_ptr(), st)),
  "bwd_x_unpack": timeit(lambda: lib.mhh_pres_bwd_x_unpack(hp.plan, hp.G, hp.xrecv.data_ptr(), f, st)),
- "halo(p)": timeit(lambda: hp.halo([hp.p])),
+ "halo(p, 1 row north)": timeit(lambda: hp.halo([hp.p], rows_south=0, rows_north=1)),
  "pres_output": timeit(lambda: lib.mhh_pres_output_order(hp.G, 2, f, st)),
  "full step (no comm)": timeit(hp.step),
 }
