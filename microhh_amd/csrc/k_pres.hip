@@ -13,6 +13,8 @@
 // bmati[kx]+bmatj[ky]), so results agree to rounding of the transform (DESIGN.md "Parity").
 #include <vector>
 #include <rocfft/rocfft.h>
+#include <cstring>
+#include <cstdlib>
 #include "k_common.h"
 
 using namespace mhh;
@@ -35,6 +37,10 @@ struct mhh_pres_plan
     void* work = nullptr;        // scratch of the k-sweep: work3d (pres_2) / 7 band arrays + rhs (pres_4)
     rocfft_plan fwd = nullptr, bwd = nullptr;
     rocfft_execution_info fwd_info = nullptr, bwd_info = nullptr;
+    // fused form (mhh_pres_exec): Pres::input rides in the forward transform as its load callback, the unpack in the inverse
+    // transform as its store callback; cb_data = device copy of the PresCb record the callbacks read
+    rocfft_execution_info fwd_info_cb = nullptr, bwd_info_cb = nullptr;
+    void* cb_data = nullptr; bool cb_ready = false;
     void* fwd_wb = nullptr; void* bwd_wb = nullptr;
     bool fft_setup = false;
 };
@@ -174,7 +180,9 @@ MHH_API void mhh_pres_plan_destroy(mhh_pres_plan* P)
     if (P->bwd) rocfft_plan_destroy(P->bwd);
     if (P->fwd_info) rocfft_execution_info_destroy(P->fwd_info);
     if (P->bwd_info) rocfft_execution_info_destroy(P->bwd_info);
-    void* bufs[] = {P->bmati, P->bmatj, P->a, P->c, P->dz, P->rhoref, P->packed, P->spec, P->work, P->fwd_wb, P->bwd_wb,
+    if (P->fwd_info_cb) rocfft_execution_info_destroy(P->fwd_info_cb);
+    if (P->bwd_info_cb) rocfft_execution_info_destroy(P->bwd_info_cb);
+    void* bufs[] = {P->cb_data, P->bmati, P->bmatj, P->a, P->c, P->dz, P->rhoref, P->packed, P->spec, P->work, P->fwd_wb, P->bwd_wb,
                     P->m[0], P->m[1], P->m[2], P->m[3], P->m[4], P->m[5], P->m[6]};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (P->fft_setup && --g_rocfft_users == 0) rocfft_cleanup();
@@ -182,6 +190,7 @@ MHH_API void mhh_pres_plan_destroy(mhh_pres_plan* P)
 }
 
 static int hdma_factor(mhh_pres_plan* P);
+static int pres_cb_setup(mhh_pres_plan* P);
 MHH_API int mhh_pres_plan_create(const mhh_grid* g, int order, const void* host_dz, const void* host_dzhi, const void* host_dzi4, const void* host_dzhi4,
                                  const void* host_rhoref, const void* host_rhorefh, mhh_pres_plan** out)
 {
@@ -207,6 +216,7 @@ MHH_API int mhh_pres_plan_create(const mhh_grid* g, int order, const void* host_
         P->fft_setup = true;
         e = make_fft(P, true, &P->fwd, &P->fwd_info, &P->fwd_wb);
         if (!e) e = make_fft(P, false, &P->bwd, &P->bwd_info, &P->bwd_wb);
+        if (!e) e = pres_cb_setup(P);
     }
     if (!e && order == 4) e = hdma_factor(P);
     if (e) { mhh_pres_plan_destroy(P); return e; }
@@ -244,6 +254,20 @@ struct WtGhostOp
     }
 };
 
+// what Pres::input does before its stencil: east-west halo of ut, north-south halo of vt, mirrored wt ghost rows (pres_4)
+static int pres_input_halos(const mhh_grid* g, int order, const mhh_fields* f, void* stream)
+{
+    if (int e = mhh_boundary_cyclic(g, f->ut, MHH_EDGE_EW, stream)) return e;
+    if (g->npy == 1 && (order == 2 || g->jtot != 1))
+        if (int e = mhh_boundary_cyclic(g, f->vt, MHH_EDGE_NS, stream)) return e;
+    if (order == 4)
+    {
+#define CALL(TF) [&]{ WtGhostOp<TF> wg{make_grid<TF>(g), mp<TF>(f->wt)}; return launch_cells(as_stream(stream), wg, g->istart, g->iend, g->jstart, g->jend, 0, 1, g->icells, g->ijcells); }()
+        if (int e = MHH_DISPATCH(g, CALL)) return e;
+#undef CALL
+    }
+    return MHH_OK;
+}
 // plan-free form, also used by the slab-decomposed driver (there the north-south halo of vt is the caller's exchange)
 MHH_API int mhh_pres_input_packed(const mhh_grid* g, int order, const mhh_fields* f, double dt, void* p_packed, void* stream)
 {
@@ -252,12 +276,9 @@ MHH_API int mhh_pres_input_packed(const mhh_grid* g, int order, const mhh_fields
     MHH_REQUIRE(order == 2 || order == 4, "order");
     MHH_REQUIRE(dt > 0., "dt");
     MHH_REQUIRE(order == 4 || (f->rhoref && f->rhorefh), "rhoref");
-    if (int e = mhh_boundary_cyclic(g, f->ut, MHH_EDGE_EW, stream)) return e;
-    if (g->npy == 1 && (order == 2 || g->jtot != 1))
-        if (int e = mhh_boundary_cyclic(g, f->vt, MHH_EDGE_NS, stream)) return e;
+    if (int e = pres_input_halos(g, order, f, stream)) return e;
     hipStream_t st = as_stream(stream);
 #define CALL(TF) [&]{ GridDev<TF> gd = make_grid<TF>(g); \
-        if (order == 4) { WtGhostOp<TF> wg{gd, mp<TF>(f->wt)}; if (int e = launch_cells(st, wg, g->istart, g->iend, g->jstart, g->jend, 0, 1, g->icells, g->ijcells)) return e; } \
         PresInOp<TF> op{gd, order, mp<TF>(p_packed), cp<TF>(f->u), cp<TF>(f->v), cp<TF>(f->w), cp<TF>(f->ut), cp<TF>(f->vt), cp<TF>(f->wt), \
                         cp<TF>(f->rhoref), cp<TF>(f->rhorefh), TF(1.)/TF(dt), TF(1./TF(dt))}; \
         return launch_interior(st, gd, g->kstart, g->kend, op); }()
@@ -483,17 +504,9 @@ __global__ void __launch_bounds__(256) unpack_kernel(TF* __restrict__ p, const T
     p[(size_t)i + (size_t)j*icells + (size_t)kd*icells*jcells] = val;
 }
 
-MHH_API int mhh_pres_solve(mhh_pres_plan* P, const mhh_grid* g, const mhh_fields* f, void* p_packed, void* stream)
+// the k-sweep per (kx, ky) column between the two transforms: Thomas (pres_2) or the factored 7-band substitution (pres_4)
+static int pres_column_solve(mhh_pres_plan* P, const mhh_grid* g, hipStream_t st)
 {
-    if (int e = check_grid(g)) return e;
-    MHH_REQUIRE(P && f && f->p, "null field");
-    MHH_REQUIRE(P->dtype == g->dtype && P->itot == g->itot && P->jtot == g->jtot && P->ktot == g->ktot, "plan/grid mismatch");
-    if (!p_packed) p_packed = P->packed;
-    hipStream_t st = as_stream(stream);
-    MHH_FFT_TRY(rocfft_execution_info_set_stream(P->fwd_info, st));
-    MHH_FFT_TRY(rocfft_execution_info_set_stream(P->bwd_info, st));
-    void* in[1] = {p_packed}; void* out[1] = {P->spec};
-    MHH_FFT_TRY(rocfft_execute(P->fwd, in, out, P->fwd_info));
     dim3 grid((P->nxh + 63)/64, P->jtot);
     if (P->order == 2)
     {
@@ -512,6 +525,21 @@ MHH_API int mhh_pres_solve(mhh_pres_plan* P, const mhh_grid* g, const mhh_fields
         else                     hipLaunchKernelGGL(hdma_solve_kernel<float>,  sg, dim3(128), 0, st, (float*)P->spec,  cp<float>(P->work),  ncol, P->ktot);
     }
     MHH_LAUNCH_CHECK();
+    return MHH_OK;
+}
+
+MHH_API int mhh_pres_solve(mhh_pres_plan* P, const mhh_grid* g, const mhh_fields* f, void* p_packed, void* stream)
+{
+    if (int e = check_grid(g)) return e;
+    MHH_REQUIRE(P && f && f->p, "null field");
+    MHH_REQUIRE(P->dtype == g->dtype && P->itot == g->itot && P->jtot == g->jtot && P->ktot == g->ktot, "plan/grid mismatch");
+    if (!p_packed) p_packed = P->packed;
+    hipStream_t st = as_stream(stream);
+    MHH_FFT_TRY(rocfft_execution_info_set_stream(P->fwd_info, st));
+    MHH_FFT_TRY(rocfft_execution_info_set_stream(P->bwd_info, st));
+    void* in[1] = {p_packed}; void* out[1] = {P->spec};
+    MHH_FFT_TRY(rocfft_execute(P->fwd, in, out, P->fwd_info));
+    if (int e = pres_column_solve(P, g, st)) return e;
     void* in2[1] = {P->spec}; void* out2[1] = {p_packed};
     MHH_FFT_TRY(rocfft_execute(P->bwd, in2, out2, P->bwd_info));
     const int nghost = (P->order == 2) ? 1 : 4;
@@ -565,9 +593,125 @@ MHH_API int mhh_pres_output_order(const mhh_grid* g, int order, const mhh_fields
 #undef CALL
 }
 
+// =======================================================================================================
+// Fused form of Pres::exec. rocFFT lets a transform obtain its input through a load callback and deliver its output
+// through a store callback (rocfft_execution_info_set_load_callback / _store_callback). Pres::input is such a producer
+// (one value per packed cell, from the six ghosted fields) and the unpack such a consumer (normalise, ghosted layout,
+// periodic halo and vertical ghost rows), so the packed right-hand side and the packed solution never exist in memory:
+// two array writes and two array reads less than the staged form, and two kernels less. The transforms themselves and the
+// arithmetic of both ends are the staged form's: same bits (tests: fused vs staged).
+// =======================================================================================================
+template<class TF> struct PresCb
+{
+    GridDev<TF> g; int order;
+    const TF* u; const TF* v; const TF* w; const TF* ut; const TF* vt; const TF* wt; const TF* rhoref; const TF* rhorefh;
+    TF dti2, dti4;
+    TF* p;
+};
+template<class TF>
+__device__ TF pres_load_cb(TF*, size_t offset, void* cbdata, void*)
+{
+    const PresCb<TF>& d = *static_cast<const PresCb<TF>*>(cbdata);
+    const GridDev<TF>& g = d.g;
+    const unsigned o = (unsigned)offset, ij = (unsigned)g.imax*(unsigned)g.jmax;
+    const unsigned kz = o / ij, r = o - kz*ij, jz = r / (unsigned)g.imax, iz = r - jz*(unsigned)g.imax;
+    const int k = (int)kz + g.kgc;
+    const int c = ((int)iz + g.igc) + ((int)jz + g.jgc)*g.icells + k*g.ijcells;
+    if (d.order == 2) return pres2_in(d.u, d.v, d.w, d.ut, d.vt, d.wt, c, g.icells, g.ijcells, g.dxi_t, g.dyi_t, d.dti2, d.rhoref[k], d.rhorefh[k], d.rhorefh[k+1], g.dzi[k]);
+    return pres4_in(d.u, d.v, d.w, d.ut, d.vt, d.wt, c, g.icells, g.ijcells, g.dxi_d, g.dyi_d, d.dti4, g.dzi4[k], g.dim3);
+}
+template<class TF>
+__device__ void pres_store_cb(TF*, size_t offset, TF value, void* cbdata, void*)
+{
+    const PresCb<TF>& d = *static_cast<const PresCb<TF>*>(cbdata);
+    const GridDev<TF>& g = d.g;
+    const int itot = g.imax, jtot = g.jmax, kmax = g.kend - g.kstart;
+    const unsigned o = (unsigned)offset, ij = (unsigned)itot*(unsigned)jtot;
+    const unsigned kz = o / ij, r = o - kz*ij, jz = r / (unsigned)itot, iz = r - jz*(unsigned)itot;
+    const TF val = value / jtot / itot;                              // as unpack_kernel (src/fft.cxx scales 1/jtot then 1/itot)
+    // destination levels: the interior one and the ghost rows that mirror it (src/pres_2.cxx:352-360, src/pres_4.cxx:508-525)
+    int kd[2]; int nk = 1; kd[0] = (int)kz + g.kgc;
+    if (d.order == 2) { if (kz == 0) kd[nk++] = g.kgc - 1; }
+    else
+    {
+        if (kz == 0) kd[nk++] = g.kgc - 1;
+        if (kz == 1) kd[nk++] = g.kgc - 2;
+        if ((int)kz == kmax-1) kd[nk++] = g.kgc + kmax;
+        if ((int)kz == kmax-2) kd[nk++] = g.kgc + kmax + 1;
+    }
+    for (int n=0; n<nk; ++n)
+        for (int jd = ((int)jz + g.jgc) % jtot; jd < g.jcells; jd += jtot)       // every row / column congruent to this one: the periodic halo
+            for (int id = ((int)iz + g.igc) % itot; id < g.icells; id += itot)
+                d.p[(size_t)id + (size_t)jd*g.icells + (size_t)kd[n]*g.ijcells] = val;
+}
+// the record travels as a kernel argument: stream-ordered, and no host buffer has to outlive the call
+template<class TF> __global__ void pres_cb_record(PresCb<TF>* dst, const PresCb<TF> src) { *dst = src; }
+template<class TF> __global__ void pres_cb_addresses(void** out) { out[0] = (void*)&pres_load_cb<TF>; out[1] = (void*)&pres_store_cb<TF>; }
+
+static int pres_cb_setup(mhh_pres_plan* P)
+{
+    // device addresses of the two callbacks, execution infos that carry them, the record they read
+    void** dptr = nullptr; void* h[2] = {nullptr, nullptr};
+    MHH_HIP_TRY(hipMalloc((void**)&dptr, 2*sizeof(void*)));
+    if (P->dtype == MHH_F64) hipLaunchKernelGGL(pres_cb_addresses<double>, dim3(1), dim3(1), 0, 0, dptr);
+    else                     hipLaunchKernelGGL(pres_cb_addresses<float>,  dim3(1), dim3(1), 0, 0, dptr);
+    hipError_t he = hipMemcpy(h, dptr, 2*sizeof(void*), hipMemcpyDeviceToHost);
+    (void)hipFree(dptr);
+    if (he != hipSuccess || !h[0] || !h[1]) { set_error("pres callbacks: address query failed"); return MHH_EHIP; }
+    MHH_HIP_TRY(hipMalloc(&P->cb_data, sizeof(PresCb<double>)));
+    MHH_FFT_TRY(rocfft_execution_info_create(&P->fwd_info_cb));
+    MHH_FFT_TRY(rocfft_execution_info_create(&P->bwd_info_cb));
+    size_t wf = 0, wb = 0;
+    MHH_FFT_TRY(rocfft_plan_get_work_buffer_size(P->fwd, &wf));
+    MHH_FFT_TRY(rocfft_plan_get_work_buffer_size(P->bwd, &wb));
+    if (wf) MHH_FFT_TRY(rocfft_execution_info_set_work_buffer(P->fwd_info_cb, P->fwd_wb, wf));
+    if (wb) MHH_FFT_TRY(rocfft_execution_info_set_work_buffer(P->bwd_info_cb, P->bwd_wb, wb));
+    void* lfn[1] = {h[0]}; void* sfn[1] = {h[1]}; void* dat[1] = {P->cb_data};
+    if (rocfft_execution_info_set_load_callback(P->fwd_info_cb, lfn, dat, 0) != rocfft_status_success) return MHH_OK;   // not supported: stay staged
+    if (rocfft_execution_info_set_store_callback(P->bwd_info_cb, sfn, dat, 0) != rocfft_status_success) return MHH_OK;
+    P->cb_ready = true;
+    return MHH_OK;
+}
+
+template<class TF>
+static int pres_exec_fused(mhh_pres_plan* P, const mhh_grid* g, const mhh_fields* f, double dt, hipStream_t st)
+{
+    PresCb<TF> h;
+    h.g = make_grid<TF>(g); h.order = P->order;
+    h.u = cp<TF>(f->u); h.v = cp<TF>(f->v); h.w = cp<TF>(f->w); h.ut = cp<TF>(f->ut); h.vt = cp<TF>(f->vt); h.wt = cp<TF>(f->wt);
+    h.rhoref = cp<TF>(f->rhoref); h.rhorefh = cp<TF>(f->rhorefh); h.dti2 = TF(1.)/TF(dt); h.dti4 = TF(1./TF(dt)); h.p = mp<TF>(f->p);
+    hipLaunchKernelGGL(pres_cb_record<TF>, dim3(1), dim3(1), 0, st, static_cast<PresCb<TF>*>(P->cb_data), h);
+    MHH_LAUNCH_CHECK();
+    MHH_FFT_TRY(rocfft_execution_info_set_stream(P->fwd_info_cb, st));
+    MHH_FFT_TRY(rocfft_execution_info_set_stream(P->bwd_info_cb, st));
+    void* in[1] = {P->packed}; void* out[1] = {P->spec};          // `packed` is never read or written: the callbacks stand in for it
+    MHH_FFT_TRY(rocfft_execute(P->fwd, in, out, P->fwd_info_cb));
+    if (int e = pres_column_solve(P, g, st)) return e;
+    void* in2[1] = {P->spec}; void* out2[1] = {P->packed};
+    MHH_FFT_TRY(rocfft_execute(P->bwd, in2, out2, P->bwd_info_cb));
+    return MHH_OK;
+}
+
 MHH_API int mhh_pres_exec(mhh_pres_plan* P, const mhh_grid* g, const mhh_fields* f, double dt, void* stream)
 {
-    if (int e = mhh_pres_input(P, g, f, dt, nullptr, stream)) return e;
-    if (int e = mhh_pres_solve(P, g, f, nullptr, stream)) return e;
+    MHH_REQUIRE(P != nullptr, "plan");
+    // Opt-in (MHH_PRES_FUSED=1). Measured on MI355X: identical bits, but the transforms run the heavy producer through an
+    // indirect call per element and lose more than the two saved array passes give back (512^3: 15.7 ms vs 14.7 ms per step;
+    // 512x256x256 pres_4: 4.05 vs 3.42 ms), so the staged form stays the default.
+    const char* env = getenv("MHH_PRES_FUSED");
+    if (!P->cb_ready || !(env && !strcmp(env, "1")))
+    {
+        if (int e = mhh_pres_input(P, g, f, dt, nullptr, stream)) return e;
+        if (int e = mhh_pres_solve(P, g, f, nullptr, stream)) return e;
+        return mhh_pres_output(P, g, f, stream);
+    }
+    if (int e = check_grid(g)) return e;
+    MHH_REQUIRE(f && f->p && f->u && f->v && f->w && f->ut && f->vt && f->wt, "null field");
+    MHH_REQUIRE(P->dtype == g->dtype && P->itot == g->itot && P->jtot == g->jtot && P->ktot == g->ktot, "plan/grid mismatch");
+    MHH_REQUIRE(dt > 0., "dt");
+    MHH_REQUIRE(P->order == 4 || (f->rhoref && f->rhorefh), "rhoref");
+    MHH_REQUIRE((unsigned long long)g->itot*g->jtot*g->ktot < (1ull << 31), "fused form indexes the packed cells with 32 bits");
+    if (int e = pres_input_halos(g, P->order, f, stream)) return e;
+    if (int e = (g->dtype == MHH_F64) ? pres_exec_fused<double>(P, g, f, dt, as_stream(stream)) : pres_exec_fused<float>(P, g, f, dt, as_stream(stream))) return e;
     return mhh_pres_output(P, g, f, stream);
 }

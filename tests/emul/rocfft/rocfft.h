@@ -15,7 +15,8 @@ enum rocfft_array_type { rocfft_array_type_complex_interleaved, rocfft_array_typ
 struct rocfft_plan_t { rocfft_transform_type type; rocfft_precision prec; size_t nd, n0, n1, batch; };
 typedef rocfft_plan_t* rocfft_plan;
 typedef int* rocfft_plan_description;
-typedef int* rocfft_execution_info;
+struct rocfft_execution_info_t { void* load_fn = nullptr; void* load_data = nullptr; void* store_fn = nullptr; void* store_data = nullptr; };
+typedef rocfft_execution_info_t* rocfft_execution_info;
 inline rocfft_status rocfft_setup() { return rocfft_status_success; }
 inline rocfft_status rocfft_cleanup() { return rocfft_status_success; }
 inline rocfft_status rocfft_plan_description_create(rocfft_plan_description* d) { *d = new int(0); return rocfft_status_success; }
@@ -25,14 +26,23 @@ inline rocfft_status rocfft_plan_description_set_data_layout(rocfft_plan_descrip
 inline rocfft_status rocfft_plan_create(rocfft_plan* p, rocfft_result_placement, rocfft_transform_type t, rocfft_precision pr, size_t nd, const size_t* len, size_t batch, rocfft_plan_description)
 { *p = new rocfft_plan_t{t, pr, nd, len[0], nd > 1 ? len[1] : 1, batch}; return rocfft_status_success; }
 inline rocfft_status rocfft_plan_destroy(rocfft_plan p) { delete p; return rocfft_status_success; }
-inline rocfft_status rocfft_execution_info_create(rocfft_execution_info* i) { *i = new int(0); return rocfft_status_success; }
+inline rocfft_status rocfft_execution_info_create(rocfft_execution_info* i) { *i = new rocfft_execution_info_t(); return rocfft_status_success; }
+// callbacks (k_pres.hip's fused form): Tdata load(Tdata*, size_t offset, void* cbdata, void*) / void store(Tdata*, size_t, Tdata, void*, void*)
+inline rocfft_status rocfft_execution_info_set_load_callback(rocfft_execution_info i, void** fn, void** data, size_t)
+{ i->load_fn = fn ? fn[0] : nullptr; i->load_data = data ? data[0] : nullptr; return rocfft_status_success; }
+inline rocfft_status rocfft_execution_info_set_store_callback(rocfft_execution_info i, void** fn, void** data, size_t)
+{ i->store_fn = fn ? fn[0] : nullptr; i->store_data = data ? data[0] : nullptr; return rocfft_status_success; }
 inline rocfft_status rocfft_execution_info_destroy(rocfft_execution_info i) { delete i; return rocfft_status_success; }
 inline rocfft_status rocfft_plan_get_work_buffer_size(rocfft_plan, size_t* n) { *n = 0; return rocfft_status_success; }
 inline rocfft_status rocfft_execution_info_set_work_buffer(rocfft_execution_info, void*, size_t) { return rocfft_status_success; }
 inline rocfft_status rocfft_execution_info_set_stream(rocfft_execution_info, void*) { return rocfft_status_success; }
 template<class T>
-inline void emul_fft_run(const rocfft_plan_t& P, void* in, void* out)
+inline void emul_fft_run(const rocfft_plan_t& P, void* in, void* out, const rocfft_execution_info_t* info)
 {
+    typedef T (*load_t)(T*, size_t, void*, void*);
+    typedef void (*store_t)(T*, size_t, T, void*, void*);
+    const load_t lcb = info ? reinterpret_cast<load_t>(info->load_fn) : nullptr;
+    const store_t scb = info ? reinterpret_cast<store_t>(info->store_fn) : nullptr;
     typedef std::complex<double> cd;
     const size_t n0 = P.n0, n1 = P.n1, nh = n0/2+1;
     const double pi = std::acos(-1.0);
@@ -55,7 +65,9 @@ inline void emul_fft_run(const rocfft_plan_t& P, void* in, void* out)
         }
         else if (P.type == rocfft_transform_type_real_forward)
         {
-            const T* r = static_cast<const T*>(in) + b*n0*n1;
+            std::vector<T> rin;
+            if (lcb) { rin.resize(n0*n1); for (size_t e=0; e<n0*n1; ++e) rin[e] = lcb(static_cast<T*>(in), b*n0*n1 + e, info->load_data, nullptr); }
+            const T* r = lcb ? rin.data() : static_cast<const T*>(in) + b*n0*n1;
             std::complex<T>* h = static_cast<std::complex<T>*>(out) + b*nh*n1;
             for (size_t ky=0; ky<n1; ++ky) for (size_t kx=0; kx<nh; ++kx)
             {
@@ -79,14 +91,15 @@ inline void emul_fft_run(const rocfft_plan_t& P, void* in, void* out)
                 cd acc = 0;
                 for (size_t ky=0; ky<n1; ++ky) for (size_t kx=0; kx<n0; ++kx)
                     acc += full[kx + ky*n0] * std::polar(1.0, 2*pi*((double)((kx*i) % n0)/n0 + (double)((ky*j) % n1)/n1));
-                r[i + j*n0] = (T)acc.real();
+                if (scb) scb(static_cast<T*>(out), b*n0*n1 + i + j*n0, (T)acc.real(), info->store_data, nullptr);
+                else r[i + j*n0] = (T)acc.real();
             }
         }
     }
 }
-inline rocfft_status rocfft_execute(rocfft_plan p, void* in[], void* out[], rocfft_execution_info)
+inline rocfft_status rocfft_execute(rocfft_plan p, void* in[], void* out[], rocfft_execution_info info)
 {
     void* o = out ? out[0] : in[0];      // in-place plans pass no output buffer
-    if (p->prec == rocfft_precision_double) emul_fft_run<double>(*p, in[0], o); else emul_fft_run<float>(*p, in[0], o);
+    if (p->prec == rocfft_precision_double) emul_fft_run<double>(*p, in[0], o, info); else emul_fft_run<float>(*p, in[0], o, info);
     return rocfft_status_success;
 }

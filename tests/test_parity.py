@@ -335,6 +335,35 @@ def test_exec_viscosity(be, sm, neutral, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("order", [2, 4])
+def test_pres_exec_callback_fused_equals_staged(be, order, dtype):
+    """mhh_pres_exec with Pres::input as the forward transform's load callback and the unpack as the inverse transform's
+    store callback, against input -> solve -> output as three stages: the same transforms, the same bits (p with all its
+    ghost cells, and the corrected tendencies)."""
+    O = cm.oracle()
+    gl = [cm.grid_2nd(16, 12, 10, gc=(1, 1, 1), dtype=dtype), cm.grid_2nd(12, 10, 8, gc=(3, 3, 1), dtype=dtype), cm.grid_2nd(12, 1, 8, gc=(1, 1, 1), dtype=dtype),
+          cm.grid_2nd(4, 3, 6, gc=(3, 3, 1), dtype=dtype)] if order == 2 else [cm.grid_4th(16, 12, 12, dtype=dtype), cm.grid_4th(12, 1, 8, dtype=dtype)]
+    for g in gl:
+        c = cm.Case(g, rho=("random" if order == 2 else "one"), periodic=True)
+        Gh = g.host_struct(); dt = 0.7
+        out = {}
+        for form in ("fused", "staged"):
+            d = B.DevCase(be, c); f = d.fields()
+            plan = capi.PLAN()
+            B.ok(be, be.lib.mhh_pres_plan_create(Gh, order, ptr(g.dz), ptr(g.dzhi), ptr(g.dzi4), ptr(g.dzhi4), ptr(c.rhoref), ptr(c.rhorefh), C.byref(plan)))
+            os.environ["MHH_PRES_FUSED"] = "1" if form == "fused" else "0"
+            try:
+                B.ok(be, be.lib.mhh_pres_exec(plan, d.G, C.byref(f), dt, be.stream))
+            finally:
+                os.environ.pop("MHH_PRES_FUSED", None)
+            out[form] = [be.host(x) for x in (d.p, d.ut, d.vt, d.wt)]
+            be.lib.mhh_pres_plan_destroy(plan)
+        for a, b, nm in zip(out["fused"], out["staged"], ("p", "ut", "vt", "wt")):
+            assert same(a, b), (order, g.shape3, nm, cm.ulp_diff(a, b))
+        assert not np.array_equal(out["fused"][0], c.p)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_fused_rhs_on_minimal_and_ragged_grids(be, dtype):
     """Smallest legal vertical extent (every level is wall-adjacent: no interior fast path), tiles narrower than a wave,
     a single row, and extents that are not multiples of the 64 x 4 tile: fused passes against the oracle's operator sequence."""
