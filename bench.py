@@ -28,6 +28,7 @@ WORKLOADS = {
     "drycblles256": ("drycblles", 256, 256, 256, "drycblles 256^3 fp64, advec_2i5 + diff_smag2 + pres_2 (BASELINE.json configs[1])"),
     "moser600": ("moser600", 512, 256, 256, "moser600 512x256x256 fp64, advec_4 + diff_4 + pres_4 (BASELINE.json configs[2])"),
     "slab8of512": ("drycblles", 512, 64, 512, "one rank's share (512x64x512) of drycblles 512^3 on 8 GPUs, run alone: per-rank compute estimate"),
+    "rehearsal": ("drycblles", 16, 24, 10, "tiny drycblles grid: contract rehearsal on the CPU (--device cpu), not a measurement"),
     "taylorgreen64": ("taylorgreen", 64, 64, 64, "taylorgreen 64^3 fp64, advec_2 + diff_2 + pres_2 (BASELINE.json configs[0])"),
     # BASELINE.json configs[4]: fp32, RHS only (exec_viscosity + advec_2i5 + diff_smag2; no pressure solve in that config)
     "gabls1_1024": ("gabls1", 1024, 1024, 256, "gabls1 1024x1024x256 fp32, advec_2i5 + diff_smag2, RHS only (BASELINE.json configs[4] grid on N GPUs)"),
@@ -92,6 +93,9 @@ def main():
     ap.add_argument("--workload", default="drycblles512", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="time Advec::exec + Diff::exec as separate launches")
+    ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
+                    help="cpu = REHEARSAL of this script's control flow (ranks, exchanges, JSON line) with gloo and the test-only CPU "
+                         "emulation of the kernels named by MHH_LIB; never a measurement")
     ap.add_argument("--force-slab", action="store_true", help="N=1 only: run the slab code path (halo pack/unpack, split pressure solve) with local copies as exchanges")
     args = ap.parse_args()
 
@@ -101,14 +105,35 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched through torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
-    torch.cuda.set_device(local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    on_gpu = args.device == "cuda"
+    if on_gpu:
+        torch.cuda.set_device(local)
+        if world > 1:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        if not os.environ.get("MHH_LIB"):
+            sys.exit("--device cpu is a rehearsal mode: point MHH_LIB at tests/emul/libmhh_emul.so")
+        if world > 1:
+            dist.init_process_group("gloo")
+
+    class Ev:                                  # HIP event on the stream the kernels run on; wall clock in the rehearsal
+        def __init__(self):
+            self.e = torch.cuda.Event(enable_timing=True) if on_gpu else None
+            self.t = 0.0
+
+        def record(self):
+            if on_gpu:
+                self.e.record()
+            else:
+                self.t = time.perf_counter()
+
+        def elapsed_time(self, other):
+            return self.e.elapsed_time(other.e) if on_gpu else 1e3 * (other.t - self.t)
 
     case, itot, jtot, ktot, desc = WORKLOADS[args.workload]
     from microhh_amd.model import HotPath
     rhs_only = args.workload in FP32_RHS_ONLY
-    hp = HotPath(case, itot, jtot, ktot, device="cuda:%d" % local, npy=world, rank=rank,   # slab in y: npx=1, npy=world
+    hp = HotPath(case, itot, jtot, ktot, device=("cuda:%d" % local if on_gpu else "cpu"), npy=world, rank=rank,   # slab in y: npx=1, npy=world
                  force_slab=(args.force_slab and world == 1), dtype=(np.float32 if rhs_only else np.float64))
 
     rhs = hp.rhs_unfused if args.unfused else hp.rhs
@@ -135,13 +160,15 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
-    events = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(args.steps)]
+    events = [tuple(Ev() for _ in range(3)) for _ in range(args.steps)]
 
     def barrier():
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            if on_gpu:
+                torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
     for n in range(args.steps):
@@ -149,7 +176,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=("cuda" if on_gpu else "cpu"), dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms = 1e3 * elapsed / args.steps
@@ -183,7 +210,9 @@ def main():
         # WRITE_SIZE in separate runs, FETCH_SIZE doubled for gfx950): profiles/r1e_kernels_pmc.md
         out["roofline"]["traffic"] = (7.295e6 * 2 + 4.265e6) * 1024
         out["roofline"]["traffic_source"] = "profiles/r1e_kernels_pmc.md"
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if not on_gpu:
+        out["data"] = "synthetic; CPU REHEARSAL of the script (emulated kernels, gloo): not a measurement"
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and on_gpu:
         out["cpu_baseline"] = cpu_baseline("drycblles" if case == "gabls1" else case)
     hp.close()
     if rank == 0:
