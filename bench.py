@@ -37,7 +37,7 @@ WORKLOADS = {
 FP32_RHS_ONLY = ("gabls1_1024", "gabls1_slab8")
 
 
-def cpu_baseline(case, sample=(128, 128, 128), reps=3):
+def cpu_baseline(case, sample=(256, 256, 128), reps=5):
     """The CPU oracle (port of the reference CPU path, -O3 -march=native, 1 thread) on a bounded sample of the
     same workload. Reported beside the GPU number; never part of the measured product path."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
