@@ -1,0 +1,56 @@
+// integration/adaptor_advec_2i5.cxx -- replaces the USECUDA half of the reference's Advec_2i5 (src/advec_2i5.cu:640-760):
+// the same member functions, forwarding to libmhh_hip.so. Plain C++: no HIP/CUDA compiler needed for this file.
+#include <algorithm>
+#include "advec_2i5.h"
+#include "grid.h"
+#include "fields.h"
+#include "stats.h"
+#include "mhh_adaptor.h"
+
+#ifdef USECUDA
+template<typename TF>
+void Advec_2i5<TF>::exec(Stats<TF>& stats)
+{
+    mhh_grid g = mhh_make_grid(grid.get_grid_data(), master.get_MPI_data());
+    mhh_fields f = mhh_make_fields(fields);
+    for (const std::string& name : fluxlimit_list)                   // src/advec_2i5.cxx:921: these scalars take the Koren limiter
+    {
+        const int n = mhh_scalar_index(fields, name);
+        if (n >= 0) f.s_fluxlimit[n] = 1;
+    }
+    mhh_check(mhh_advec_exec(&g, MHH_ADVEC_2I5, &f, /*stream*/ nullptr));
+    stats.calc_tend(*fields.mt.at("u"), tend_name);
+    stats.calc_tend(*fields.mt.at("v"), tend_name);
+    stats.calc_tend(*fields.mt.at("w"), tend_name);
+    for (auto& it : fields.st)
+        stats.calc_tend(*it.second, tend_name);
+}
+
+template<typename TF>
+double Advec_2i5<TF>::get_cfl(const double dt)
+{
+    mhh_grid g = mhh_make_grid(grid.get_grid_data(), master.get_MPI_data());
+    double cfl = 0;
+    auto tmp = fields.get_tmp_g();                                    // scratch of the reduction, released before return
+    mhh_check(mhh_advec_cfl(&g, MHH_ADVEC_2I5, fields.mp.at("u")->fld_g, fields.mp.at("v")->fld_g, fields.mp.at("w")->fld_g,
+                            dt, tmp->fld_g, &cfl, nullptr));
+    fields.release_tmp_g(tmp);
+    master.max(&cfl, 1);                                              // the cross-rank reduction stays the host's
+    return cfl;
+}
+
+template<typename TF>
+unsigned long Advec_2i5<TF>::get_time_limit(unsigned long idt, double dt)
+{
+    double cfl = get_cfl(dt);
+    cfl = std::max(cflmin, cfl);
+    return idt * cflmax / cfl;
+}
+
+template void Advec_2i5<double>::exec(Stats<double>&);
+template double Advec_2i5<double>::get_cfl(double);
+template unsigned long Advec_2i5<double>::get_time_limit(unsigned long, double);
+template void Advec_2i5<float>::exec(Stats<float>&);
+template double Advec_2i5<float>::get_cfl(double);
+template unsigned long Advec_2i5<float>::get_time_limit(unsigned long, double);
+#endif
