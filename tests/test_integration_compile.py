@@ -24,4 +24,5 @@ def test_adaptor_type_checks_against_reference_headers(src):
 
 def test_adaptors_exist():
     names = {os.path.basename(p) for p in glob.glob(os.path.join(cm.ROOT, "integration", "*"))}
-    assert {"mhh_adaptor.h", "adaptor_advec_2i5.cxx", "adaptor_diff_smag2.cxx", "adaptor_boundary_cyclic.cxx"} <= names
+    assert {"mhh_adaptor.h", "adaptor_advec_2.cxx", "adaptor_advec_2i5.cxx", "adaptor_advec_4.cxx", "adaptor_diff_2.cxx", "adaptor_diff_4.cxx",
+            "adaptor_diff_smag2.cxx", "adaptor_boundary_cyclic.cxx"} <= names
