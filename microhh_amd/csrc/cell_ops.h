@@ -149,6 +149,22 @@ MHH_HD TF advec25_ver(const TF* __restrict__ f, int c, int kk, int ot, int ob, T
     return cen;
 }
 
+// advec_2i4 (src/advec_2i4.cxx:101-640): 2nd-order advecting velocities, 4th-order (-1,9,9,-1)/16 interpolation of the
+// advected field, 2nd order on the vertical faces next to a wall; ONE increment per cell (x, y and z terms in one sum).
+// ot / ob = order of the top / bottom vertical face: the 2i5 table capped at 4 (0 = wall, 2, 4).
+template<class TF>
+MHH_HD TF advec24(const TF* __restrict__ f, int c, int jj, int kk, TF ue, TF uw, TF vn, TF vs, TF wt, TF wb,
+                  int ot, int ob, TF dxi, TF dyi, TF rt, TF rb, TF rc, TF dz)
+{
+    const TF It = (ot == 0) ? TF(0) : (ot == 2) ? i2(f[c], f[c+kk]) : i4c(f[c-kk], f[c], f[c+kk], f[c+2*kk]);
+    const TF Ib = (ob == 0) ? TF(0) : (ob == 2) ? i2(f[c-kk], f[c]) : i4c(f[c-2*kk], f[c-kk], f[c], f[c+kk]);
+    const TF X = ue * i4c(f[c-1 ], f[c], f[c+1 ], f[c+2   ]) - uw * i4c(f[c-2   ], f[c-1 ], f[c], f[c+1 ]);
+    const TF Y = vn * i4c(f[c-jj], f[c], f[c+jj], f[c+2*jj]) - vs * i4c(f[c-2*jj], f[c-jj], f[c], f[c+jj]);
+    if (ob == 0) return - ( X ) * dxi - ( Y ) * dyi - ( rt * wt * It ) / rc * dz;
+    if (ot == 0) return - ( X ) * dxi - ( Y ) * dyi - ( -rb * wb * Ib ) / rc * dz;
+    return - ( X ) * dxi - ( Y ) * dyi - ( rt * wt * It - rb * wb * Ib ) / rc * dz;
+}
+
 // Thermo_dry buoyancy tendency of w (src/thermo_dry.cxx:165-197): grav/threfh[k] * (th at the w level - threfh[k])
 template<class TF>
 MHH_HD TF buoyancy_tend(const TF* __restrict__ th, int c, int kk, int order, TF grav, TF threfh_k)
@@ -291,6 +307,9 @@ MHH_HD TF cfl_cell(int scheme, const TF* __restrict__ u, const TF* __restrict__ 
 {
     if (scheme == 2)
         return tabs(i2(u[c], u[c+1]))*dxi + tabs(i2(v[c], v[c+jj]))*dyi + tabs(i2(w[c], w[c+kk]))*dzi_k;
+    if (scheme == 24)       // src/advec_2i4.cxx:51-99
+        return tabs(i4c(u[c-1], u[c], u[c+1], u[c+2]))*dxi + tabs(i4c(v[c-jj], v[c], v[c+jj], v[c+2*jj]))*dyi
+             + tabs((k == kstart || k == kend-1) ? i2(w[c], w[c+kk]) : i4c(w[c-kk], w[c], w[c+kk], w[c+2*kk]))*dzi_k;
     if (scheme == 4)
         return tabs(i4c(u[c-1], u[c], u[c+1], u[c+2]))*dxi + tabs(i4c(v[c-jj], v[c], v[c+jj], v[c+2*jj]))*dyi
              + tabs(i4c(w[c-kk], w[c], w[c+kk], w[c+2*kk]))*dzi_k;

@@ -149,7 +149,7 @@ struct AdvecOp
             else           t[c] += advec2_mom(f, u, v, w, c, o, jj, kk, g.dxi_t, g.dyi_t, rt, rb, rc, dz);
             return;
         }
-        // 2i5: horizontal then vertical, two separate accumulations (src/advec_2i5.cxx:187,210)
+        // 2i5: horizontal then vertical, two separate accumulations (src/advec_2i5.cxx:187,210); 2i4: one accumulation
         TF ue, uw, vn, vs, wtp, wbt; int ot, ob;
         if (comp == 3)
         {
@@ -164,6 +164,11 @@ struct AdvecOp
             if (isw) { ot = order_face_w(k, g.kstart, g.kend); ob = order_face_w(k-1, g.kstart, g.kend); }
             else     { ot = order_face_c(k+1, g.kstart, g.kend); ob = order_face_c(k, g.kstart, g.kend); }
         }
+        if (scheme == MHH_ADVEC_2I4)
+        {
+            t[c] += advec24(f, c, jj, kk, ue, uw, vn, vs, wtp, wbt, ot > 4 ? 4 : ot, ob > 4 ? 4 : ob, g.dxi_d, g.dyi_d, rt, rb, rc, dz);
+            return;
+        }
         TF x = t[c];
         x += advec25_hor(f, c, jj, ue, uw, vn, vs, g.dxi_t, g.dyi_t);
         x += advec25_ver(f, c, kk, ot, ob, wtp, wbt, rt, rb, rc, dz);
@@ -174,7 +179,8 @@ struct AdvecOp
 static int check_advec(const mhh_grid* g, int scheme)
 {
     if (int e = check_grid(g)) return e;
-    MHH_REQUIRE(scheme == MHH_ADVEC_2 || scheme == MHH_ADVEC_2I5 || scheme == MHH_ADVEC_4, "scheme must be 2, 25 or 4");
+    MHH_REQUIRE(scheme == MHH_ADVEC_2 || scheme == MHH_ADVEC_2I5 || scheme == MHH_ADVEC_4 || scheme == MHH_ADVEC_2I4, "scheme must be 2, 24, 25 or 4");
+    if (scheme == MHH_ADVEC_2I4) MHH_REQUIRE(g->igc >= 2 && g->jgc >= 2 && g->kgc >= 1 && g->ktot >= 4, "advec_2i4 needs gc(2,2,1) and ktot >= 4 (the reference asks for gc(2,2,2), src/advec_2i4.cxx:38-41)");
     if (scheme == MHH_ADVEC_2)   MHH_REQUIRE(g->igc >= 1 && g->jgc >= 1 && g->kgc >= 1, "advec_2 needs 1 ghost cell");
     if (scheme == MHH_ADVEC_2I5) MHH_REQUIRE(g->igc >= 3 && g->jgc >= 3 && g->kgc >= 1 && g->ktot >= 6, "advec_2i5 needs gc(3,3,1), ktot>=6 (src/advec_2i5.cxx:42-45)");
     if (scheme == MHH_ADVEC_4)   MHH_REQUIRE(g->igc >= 3 && g->jgc >= 3 && g->kgc >= 3 && g->ktot >= 2, "advec_4 needs gc(3,3,3)");

@@ -185,7 +185,7 @@ double advec_cfl(const mhh_grid& g, int scheme, const TF* u, const TF* v, const 
     const int jj = g.icells, kk = g.ijcells;
     const TF* dzi = P<TF>(g.dzi);
     TF dxi, dyi;
-    if (scheme == MHH_ADVEC_4) { dxi = TF(1.)/TF(g.dx); dyi = TF(1.)/TF(g.dy); }
+    if (scheme == MHH_ADVEC_4) { dxi = TF(1.)/TF(g.dx); dyi = TF(1.)/TF(g.dy); }   // 2, 2i4, 2i5: Grid_data::dxi
     else { dxi = TF(1./TF(g.dx)); dyi = TF(1./TF(g.dy)); }   // "1./dx" evaluated in double, narrowed
     TF cfl = 0;
     for (int k=g.kstart; k<g.kend; ++k)
@@ -195,6 +195,10 @@ double advec_cfl(const mhh_grid& g, int scheme, const TF* u, const TF* v, const 
             TF a;
             if (scheme == MHH_ADVEC_2)
                 a = std::abs(i2(u[c], u[c+1]))*dxi + std::abs(i2(v[c], v[c+jj]))*dyi + std::abs(i2(w[c], w[c+kk]))*dzi[k];
+            else if (scheme == MHH_ADVEC_2I4)                       // src/advec_2i4.cxx:51-99
+                a = std::abs(i4c(u[c-1], u[c], u[c+1], u[c+2]))*dxi
+                  + std::abs(i4c(v[c-jj], v[c], v[c+jj], v[c+2*jj]))*dyi
+                  + std::abs((k == g.kstart || k == g.kend-1) ? i2(w[c], w[c+kk]) : i4c(w[c-kk], w[c], w[c+kk], w[c+2*kk]))*dzi[k];
             else if (scheme == MHH_ADVEC_4)
                 a = std::abs(i4c(u[c-1], u[c], u[c+1], u[c+2]))*dxi
                   + std::abs(i4c(v[c-jj], v[c], v[c+jj], v[c+2*jj]))*dyi
@@ -1402,11 +1406,62 @@ ORC_API void orc_boundary_cyclic(const mhh_grid* g, void* a, int edge)
 ORC_API void orc_boundary_cyclic_2d(const mhh_grid* g, void* a)
 { DISPATCH(g, cyclic_2d<double>(*g, D(a)), cyclic_2d<float>(*g, F(a))); }
 
+namespace {
+// -------------------------------------------------------------------------------------------------------
+// advec_2i4 (src/advec_2i4.cxx:101-640): second-order fluxes, advected quantity interpolated with (-1, 9, 9, -1)/16,
+// two-point interpolation on the vertical faces next to a wall. Restated with the face-order table of the 2i5 scheme
+// capped at 4; comp 0..2 = u, v, w (staggering offset o), 3 = scalar. One increment per cell.
+// -------------------------------------------------------------------------------------------------------
+template<class TF>
+void advec24_any(const mhh_grid& g, int comp, TF* t, const TF* f, const TF* u, const TF* v, const TF* w,
+                 const TF* rhoref, const TF* rhorefh)
+{
+    const int jj = g.icells, kk = g.ijcells;
+    const TF dxi = TF(1./TF(g.dx)), dyi = TF(1./TF(g.dy));          // Grid_data::dxi (src/grid.cxx), not TF(1.)/dx
+    const TF* dzi = P<TF>(g.dzi); const TF* dzhi = P<TF>(g.dzhi);
+    const int o = (comp==0) ? -1 : (comp==1) ? -jj : (comp==2) ? -kk : 0;
+    const int k0 = (comp==2) ? g.kstart+1 : g.kstart;
+    auto cap = [](int order) { return order > 4 ? 4 : order; };
+    for (int k=k0; k<g.kend; ++k)
+    {
+        int ot, ob; TF rt, rb, rc, dz;
+        if (comp == 2) { ot = cap(face_order_w(g, k));   ob = cap(face_order_w(g, k-1)); rt = rhoref[k];    rb = rhoref[k-1]; rc = rhorefh[k]; dz = dzhi[k]; }
+        else           { ot = cap(face_order_c(g, k+1)); ob = cap(face_order_c(g, k));   rt = rhorefh[k+1]; rb = rhorefh[k];  rc = rhoref[k];  dz = dzi[k];  }
+        FOR_INTERIOR_PLANE(g)
+        {
+            const int c = i + j*jj + k*kk;
+            TF ue, uw, vn, vs, wt, wb;
+            if (comp == 3) { ue = u[c+1]; uw = u[c]; vn = v[c+jj]; vs = v[c]; wt = w[c+kk]; wb = w[c]; }
+            else
+            {
+                ue = i2(u[c+1+o], u[c+1]);  uw = i2(u[c+o], u[c]);
+                vn = i2(v[c+jj+o], v[c+jj]); vs = i2(v[c+o], v[c]);
+                wt = i2(w[c+kk+o], w[c+kk]); wb = i2(w[c+o], w[c]);
+            }
+            const TF fx = ue * i4c(f[c-1], f[c], f[c+1], f[c+2]) - uw * i4c(f[c-2], f[c-1], f[c], f[c+1]);
+            const TF fy = vn * i4c(f[c-jj], f[c], f[c+jj], f[c+2*jj]) - vs * i4c(f[c-2*jj], f[c-jj], f[c], f[c+jj]);
+            const TF top = (ot == 0) ? TF(0) : rt * wt * ((ot == 2) ? i2(f[c], f[c+kk]) : i4c(f[c-kk], f[c], f[c+kk], f[c+2*kk]));
+            TF fz;
+            if (ob == 0)      fz = top;
+            else
+            {
+                const TF Ib = (ob == 2) ? i2(f[c-kk], f[c]) : i4c(f[c-2*kk], f[c-kk], f[c], f[c+kk]);
+                if (ot == 0)  fz = -rb * wb * Ib;
+                else          fz = top - rb * wb * Ib;
+            }
+            t[c] += - fx * dxi - fy * dyi - fz / rc * dz;
+        }
+    }
+}
+
+}
+
 template<class TF>
 static void advec_mom_t(const mhh_grid& g, int scheme, int comp, void* t, const void* u, const void* v, const void* w, const void* r, const void* rh)
 {
     if (scheme == MHH_ADVEC_2)        advec2_mom<TF>(g, comp, P<TF>(t), P<TF>(u), P<TF>(v), P<TF>(w), P<TF>(r), P<TF>(rh));
     else if (scheme == MHH_ADVEC_2I5) advec25_mom<TF>(g, comp, P<TF>(t), P<TF>(u), P<TF>(v), P<TF>(w), P<TF>(r), P<TF>(rh));
+    else if (scheme == MHH_ADVEC_2I4) advec24_any<TF>(g, comp, P<TF>(t), comp==0 ? P<TF>(u) : comp==1 ? P<TF>(v) : P<TF>(w), P<TF>(u), P<TF>(v), P<TF>(w), P<TF>(r), P<TF>(rh));
     else                              advec4_mom<TF>(g, comp, P<TF>(t), P<TF>(u), P<TF>(v), P<TF>(w));
 }
 ORC_API void orc_advec_u(const mhh_grid* g, int scheme, void* t, const void* u, const void* v, const void* w, const void* r, const void* rh)
@@ -1421,6 +1476,7 @@ static void advec_s_t(const mhh_grid& g, int scheme, void* t, const void* s, con
 {
     if (scheme == MHH_ADVEC_2)        advec2_s<TF>(g, P<TF>(t), P<TF>(s), P<TF>(u), P<TF>(v), P<TF>(w), P<TF>(r), P<TF>(rh));
     else if (scheme == MHH_ADVEC_2I5) advec25_s<TF>(g, P<TF>(t), P<TF>(s), P<TF>(u), P<TF>(v), P<TF>(w), P<TF>(r), P<TF>(rh));
+    else if (scheme == MHH_ADVEC_2I4) advec24_any<TF>(g, 3, P<TF>(t), P<TF>(s), P<TF>(u), P<TF>(v), P<TF>(w), P<TF>(r), P<TF>(rh));
     else                              advec4_s<TF>(g, P<TF>(t), P<TF>(s), P<TF>(u), P<TF>(v), P<TF>(w));
 }
 ORC_API void orc_advec_s(const mhh_grid* g, int scheme, void* t, const void* s, const void* u, const void* v, const void* w, const void* r, const void* rh)
