@@ -165,6 +165,17 @@ MHH_HD TF advec24(const TF* __restrict__ f, int c, int jj, int kk, TF ue, TF uw,
     return - ( X ) * dxi - ( Y ) * dyi - ( rt * wt * It - rb * wb * Ib ) / rc * dz;
 }
 
+// advec_2i62 (src/advec_2i62.cxx:105-310): 6th-order interpolation of the advected field horizontally, two-point
+// interpolation vertically on every level; one increment per cell.
+template<class TF>
+MHH_HD TF advec262(const TF* __restrict__ f, int c, int jj, int kk, TF ue, TF uw, TF vn, TF vs, TF wt, TF wb,
+                   TF dxi, TF dyi, TF rt, TF rb, TF rc, TF dz)
+{
+    return - ( ue * i6(f[c-2   ], f[c-1 ], f[c], f[c+1 ], f[c+2   ], f[c+3   ]) - uw * i6(f[c-3   ], f[c-2   ], f[c-1 ], f[c], f[c+1 ], f[c+2   ]) ) * dxi
+           - ( vn * i6(f[c-2*jj], f[c-jj], f[c], f[c+jj], f[c+2*jj], f[c+3*jj]) - vs * i6(f[c-3*jj], f[c-2*jj], f[c-jj], f[c], f[c+jj], f[c+2*jj]) ) * dyi
+           - ( rt * wt * i2(f[c], f[c+kk]) - rb * wb * i2(f[c-kk], f[c]) ) / rc * dz;
+}
+
 // Thermo_dry buoyancy tendency of w (src/thermo_dry.cxx:165-197): grav/threfh[k] * (th at the w level - threfh[k])
 template<class TF>
 MHH_HD TF buoyancy_tend(const TF* __restrict__ th, int c, int kk, int order, TF grav, TF threfh_k)
@@ -307,6 +318,9 @@ MHH_HD TF cfl_cell(int scheme, const TF* __restrict__ u, const TF* __restrict__ 
 {
     if (scheme == 2)
         return tabs(i2(u[c], u[c+1]))*dxi + tabs(i2(v[c], v[c+jj]))*dyi + tabs(i2(w[c], w[c+kk]))*dzi_k;
+    if (scheme == 262)      // src/advec_2i62.cxx:58-105
+        return tabs(i6(u[c-2], u[c-1], u[c], u[c+1], u[c+2], u[c+3]))*dxi + tabs(i6(v[c-2*jj], v[c-jj], v[c], v[c+jj], v[c+2*jj], v[c+3*jj]))*dyi
+             + tabs(i2(w[c], w[c+kk]))*dzi_k;
     if (scheme == 24)       // src/advec_2i4.cxx:51-99
         return tabs(i4c(u[c-1], u[c], u[c+1], u[c+2]))*dxi + tabs(i4c(v[c-jj], v[c], v[c+jj], v[c+2*jj]))*dyi
              + tabs((k == kstart || k == kend-1) ? i2(w[c], w[c+kk]) : i4c(w[c-kk], w[c], w[c+kk], w[c+2*kk]))*dzi_k;

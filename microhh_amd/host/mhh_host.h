@@ -220,7 +220,7 @@ class Advec
             fluxlimit_list(std::move(fluxlimit_listin)), grid(gridin), fields(fieldsin), scheme(schemein), cflmax(cflmaxin), cflmin(1.e-5), work(nullptr)
         {
             // src/advec_2i5.cxx:39-45: the limited scalars need a second vertical ghost level
-            if (!fluxlimit_list.empty() && scheme != MHH_ADVEC_2I5) throw std::runtime_error("fluxlimit_list is an option of swadvec=2i5");
+            if (!fluxlimit_list.empty() && scheme != MHH_ADVEC_2I5 && scheme != MHH_ADVEC_2I62) throw std::runtime_error("fluxlimit_list is an option of swadvec=2i5 and 2i62");
             if (!fluxlimit_list.empty() && grid.get_grid_data().kgc < 2) throw std::runtime_error("fluxlimit_list needs kgc >= 2");
         }
         virtual ~Advec() {}
@@ -230,7 +230,7 @@ class Advec
         {
             int s;
             if (swadvec == "2") s = MHH_ADVEC_2; else if (swadvec == "2i5") s = MHH_ADVEC_2I5; else if (swadvec == "4") s = MHH_ADVEC_4;
-            else if (swadvec == "2i4") s = MHH_ADVEC_2I4;
+            else if (swadvec == "2i4") s = MHH_ADVEC_2I4; else if (swadvec == "2i62") s = MHH_ADVEC_2I62;
             else throw std::runtime_error("\"" + swadvec + "\" is an illegal value for swadvec");
             return std::make_shared<Advec>(g, f, s, cflmax, std::move(fluxlimit_list));
         }

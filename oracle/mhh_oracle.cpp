@@ -195,6 +195,10 @@ double advec_cfl(const mhh_grid& g, int scheme, const TF* u, const TF* v, const 
             TF a;
             if (scheme == MHH_ADVEC_2)
                 a = std::abs(i2(u[c], u[c+1]))*dxi + std::abs(i2(v[c], v[c+jj]))*dyi + std::abs(i2(w[c], w[c+kk]))*dzi[k];
+            else if (scheme == MHH_ADVEC_2I62)                      // src/advec_2i62.cxx:58-105
+                a = std::abs(i6(u[c-2], u[c-1], u[c], u[c+1], u[c+2], u[c+3]))*dxi
+                  + std::abs(i6(v[c-2*jj], v[c-jj], v[c], v[c+jj], v[c+2*jj], v[c+3*jj]))*dyi
+                  + std::abs(i2(w[c], w[c+kk]))*dzi[k];
             else if (scheme == MHH_ADVEC_2I4)                       // src/advec_2i4.cxx:51-99
                 a = std::abs(i4c(u[c-1], u[c], u[c+1], u[c+2]))*dxi
                   + std::abs(i4c(v[c-jj], v[c], v[c+jj], v[c+2*jj]))*dyi
@@ -1456,11 +1460,45 @@ void advec24_any(const mhh_grid& g, int comp, TF* t, const TF* f, const TF* u, c
 
 }
 
+namespace {
+// advec_2i62 (src/advec_2i62.cxx:105-310): 6th-order interpolation of the advected quantity on the x and y faces,
+// two-point interpolation on the z faces of every level; comp 0..2 = u, v, w, 3 = scalar.
+template<class TF>
+void advec262_any(const mhh_grid& g, int comp, TF* t, const TF* f, const TF* u, const TF* v, const TF* w, const TF* rhoref, const TF* rhorefh)
+{
+    const int jj = g.icells, kk = g.ijcells;
+    const TF dxi = TF(1.)/TF(g.dx), dyi = TF(1.)/TF(g.dy);
+    const TF* dzi = P<TF>(g.dzi); const TF* dzhi = P<TF>(g.dzhi);
+    const int o = (comp==0) ? -1 : (comp==1) ? -jj : (comp==2) ? -kk : 0;
+    for (int k=(comp==2 ? g.kstart+1 : g.kstart); k<g.kend; ++k)
+    {
+        const TF rt = (comp==2) ? rhoref[k] : rhorefh[k+1], rb = (comp==2) ? rhoref[k-1] : rhorefh[k];
+        const TF rc = (comp==2) ? rhorefh[k] : rhoref[k], dz = (comp==2) ? dzhi[k] : dzi[k];
+        FOR_INTERIOR_PLANE(g)
+        {
+            const int c = i + j*jj + k*kk;
+            TF ue, uw, vn, vs, wt, wb;
+            if (comp == 3) { ue = u[c+1]; uw = u[c]; vn = v[c+jj]; vs = v[c]; wt = w[c+kk]; wb = w[c]; }
+            else
+            {
+                ue = i2(u[c+1+o], u[c+1]);  uw = i2(u[c+o], u[c]);
+                vn = i2(v[c+jj+o], v[c+jj]); vs = i2(v[c+o], v[c]);
+                wt = i2(w[c+kk+o], w[c+kk]); wb = i2(w[c+o], w[c]);
+            }
+            t[c] += - ( ue * i6(f[c-2], f[c-1], f[c], f[c+1], f[c+2], f[c+3]) - uw * i6(f[c-3], f[c-2], f[c-1], f[c], f[c+1], f[c+2]) ) * dxi
+                    - ( vn * i6(f[c-2*jj], f[c-jj], f[c], f[c+jj], f[c+2*jj], f[c+3*jj]) - vs * i6(f[c-3*jj], f[c-2*jj], f[c-jj], f[c], f[c+jj], f[c+2*jj]) ) * dyi
+                    - ( rt * wt * i2(f[c], f[c+kk]) - rb * wb * i2(f[c-kk], f[c]) ) / rc * dz;
+        }
+    }
+}
+}
+
 template<class TF>
 static void advec_mom_t(const mhh_grid& g, int scheme, int comp, void* t, const void* u, const void* v, const void* w, const void* r, const void* rh)
 {
     if (scheme == MHH_ADVEC_2)        advec2_mom<TF>(g, comp, P<TF>(t), P<TF>(u), P<TF>(v), P<TF>(w), P<TF>(r), P<TF>(rh));
     else if (scheme == MHH_ADVEC_2I5) advec25_mom<TF>(g, comp, P<TF>(t), P<TF>(u), P<TF>(v), P<TF>(w), P<TF>(r), P<TF>(rh));
+    else if (scheme == MHH_ADVEC_2I62) advec262_any<TF>(g, comp, P<TF>(t), comp==0 ? P<TF>(u) : comp==1 ? P<TF>(v) : P<TF>(w), P<TF>(u), P<TF>(v), P<TF>(w), P<TF>(r), P<TF>(rh));
     else if (scheme == MHH_ADVEC_2I4) advec24_any<TF>(g, comp, P<TF>(t), comp==0 ? P<TF>(u) : comp==1 ? P<TF>(v) : P<TF>(w), P<TF>(u), P<TF>(v), P<TF>(w), P<TF>(r), P<TF>(rh));
     else                              advec4_mom<TF>(g, comp, P<TF>(t), P<TF>(u), P<TF>(v), P<TF>(w));
 }
@@ -1476,6 +1514,7 @@ static void advec_s_t(const mhh_grid& g, int scheme, void* t, const void* s, con
 {
     if (scheme == MHH_ADVEC_2)        advec2_s<TF>(g, P<TF>(t), P<TF>(s), P<TF>(u), P<TF>(v), P<TF>(w), P<TF>(r), P<TF>(rh));
     else if (scheme == MHH_ADVEC_2I5) advec25_s<TF>(g, P<TF>(t), P<TF>(s), P<TF>(u), P<TF>(v), P<TF>(w), P<TF>(r), P<TF>(rh));
+    else if (scheme == MHH_ADVEC_2I62) advec262_any<TF>(g, 3, P<TF>(t), P<TF>(s), P<TF>(u), P<TF>(v), P<TF>(w), P<TF>(r), P<TF>(rh));
     else if (scheme == MHH_ADVEC_2I4) advec24_any<TF>(g, 3, P<TF>(t), P<TF>(s), P<TF>(u), P<TF>(v), P<TF>(w), P<TF>(r), P<TF>(rh));
     else                              advec4_s<TF>(g, P<TF>(t), P<TF>(s), P<TF>(u), P<TF>(v), P<TF>(w));
 }

@@ -25,7 +25,7 @@ def grids4(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("scheme,refname", [(cm.ADVEC_2, "ref_advec_2"), (cm.ADVEC_2I5, "ref_advec_2i5"), (cm.ADVEC_2I4, "ref_advec_2i4"), (cm.ADVEC_4, "ref_advec_4")])
+@pytest.mark.parametrize("scheme,refname", [(cm.ADVEC_2, "ref_advec_2"), (cm.ADVEC_2I5, "ref_advec_2i5"), (cm.ADVEC_2I4, "ref_advec_2i4"), (cm.ADVEC_2I62, "ref_advec_2i62"), (cm.ADVEC_4, "ref_advec_4")])
 def test_advec_bitwise(scheme, refname, dtype):
     O = cm.oracle()
     for g in (grids4(dtype) if scheme == cm.ADVEC_4 else grids2(dtype)):

@@ -97,7 +97,7 @@ def test_advec_s_lim_bitexact(be, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("scheme", [cm.ADVEC_2, cm.ADVEC_2I5, cm.ADVEC_2I4, cm.ADVEC_4])
+@pytest.mark.parametrize("scheme", [cm.ADVEC_2, cm.ADVEC_2I5, cm.ADVEC_2I4, cm.ADVEC_2I62, cm.ADVEC_4])
 def test_advec_kernels_bitexact(be, scheme, dtype):
     O = cm.oracle()
     for g in (grids4(dtype) if scheme == cm.ADVEC_4 else grids2(dtype)):
