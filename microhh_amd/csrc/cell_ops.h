@@ -329,7 +329,7 @@ MHH_HD TF cfl_cell(int scheme, const TF* __restrict__ u, const TF* __restrict__ 
              + tabs(i4c(w[c-kk], w[c], w[c+kk], w[c+2*kk]))*dzi_k;
     TF wi;
     if (k == kstart || k == kend-1)        wi = i2(w[c], w[c+kk]);
-    else if (k == kstart+1 || k == kend-2) wi = i4ws(w[c-kk], w[c], w[c+kk], w[c+2*kk]);
+    else if (k == kstart+1 || k == kend-2 || scheme == 253) wi = i4ws(w[c-kk], w[c], w[c+kk], w[c+2*kk]);   // 2i53: 4th order on every inner level
     else                                   wi = i6(w[c-2*kk], w[c-kk], w[c], w[c+kk], w[c+2*kk], w[c+3*kk]);
     return tabs(i6(u[c-2], u[c-1], u[c], u[c+1], u[c+2], u[c+3]))*dxi
          + tabs(i6(v[c-2*jj], v[c-jj], v[c], v[c+jj], v[c+2*jj], v[c+3*jj]))*dyi

@@ -164,6 +164,7 @@ struct AdvecOp
             if (isw) { ot = order_face_w(k, g.kstart, g.kend); ob = order_face_w(k-1, g.kstart, g.kend); }
             else     { ot = order_face_c(k+1, g.kstart, g.kend); ob = order_face_c(k, g.kstart, g.kend); }
         }
+        if (scheme == MHH_ADVEC_2I53) { ot = ot > 4 ? 4 : ot; ob = ob > 4 ? 4 : ob; }     // src/advec_2i53.cxx: 4th/3rd order vertically
         if (scheme == MHH_ADVEC_2I62)
         {
             t[c] += advec262(f, c, jj, kk, ue, uw, vn, vs, wtp, wbt, g.dxi_t, g.dyi_t, rt, rb, rc, dz);
@@ -184,7 +185,8 @@ struct AdvecOp
 static int check_advec(const mhh_grid* g, int scheme)
 {
     if (int e = check_grid(g)) return e;
-    MHH_REQUIRE(scheme == MHH_ADVEC_2 || scheme == MHH_ADVEC_2I5 || scheme == MHH_ADVEC_4 || scheme == MHH_ADVEC_2I4 || scheme == MHH_ADVEC_2I62, "scheme must be 2, 24, 25, 262 or 4");
+    MHH_REQUIRE(scheme == MHH_ADVEC_2 || scheme == MHH_ADVEC_2I5 || scheme == MHH_ADVEC_4 || scheme == MHH_ADVEC_2I4 || scheme == MHH_ADVEC_2I62 || scheme == MHH_ADVEC_2I53, "scheme must be 2, 24, 25, 253, 262 or 4");
+    if (scheme == MHH_ADVEC_2I53) MHH_REQUIRE(g->igc >= 3 && g->jgc >= 3 && g->kgc >= 1 && g->ktot >= 4, "advec_2i53 needs gc(3,3,1), ktot >= 4");
     if (scheme == MHH_ADVEC_2I62) MHH_REQUIRE(g->igc >= 3 && g->jgc >= 3 && g->kgc >= 1, "advec_2i62 needs gc(3,3,1) (src/advec_2i62.cxx:42-45)");
     if (scheme == MHH_ADVEC_2I4) MHH_REQUIRE(g->igc >= 2 && g->jgc >= 2 && g->kgc >= 1 && g->ktot >= 4, "advec_2i4 needs gc(2,2,1) and ktot >= 4 (the reference asks for gc(2,2,2), src/advec_2i4.cxx:38-41)");
     if (scheme == MHH_ADVEC_2)   MHH_REQUIRE(g->igc >= 1 && g->jgc >= 1 && g->kgc >= 1, "advec_2 needs 1 ghost cell");

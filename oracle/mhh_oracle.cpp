@@ -211,7 +211,7 @@ double advec_cfl(const mhh_grid& g, int scheme, const TF* u, const TF* v, const 
             {
                 TF wi;
                 if (k == g.kstart || k == g.kend-1)         wi = i2(w[c], w[c+kk]);
-                else if (k == g.kstart+1 || k == g.kend-2)  wi = i4ws(w[c-kk], w[c], w[c+kk], w[c+2*kk]);
+                else if (k == g.kstart+1 || k == g.kend-2 || scheme == MHH_ADVEC_2I53)  wi = i4ws(w[c-kk], w[c], w[c+kk], w[c+2*kk]);   // 2i53: 4th order on every inner level
                 else                                        wi = i6(w[c-2*kk], w[c-kk], w[c], w[c+kk], w[c+2*kk], w[c+3*kk]);
                 a = std::abs(i6(u[c-2], u[c-1], u[c], u[c+1], u[c+2], u[c+3]))*dxi
                   + std::abs(i6(v[c-2*jj], v[c-jj], v[c], v[c+jj], v[c+2*jj], v[c+3*jj]))*dyi
@@ -276,7 +276,7 @@ inline TF vert_incr(int ot, int ob, TF rt, TF rb, TF rc, TF dz, TF wt, TF wb, TF
 
 template<class TF>
 void advec25_mom(const mhh_grid& g, int comp, TF* t, const TF* u, const TF* v, const TF* w,
-                 const TF* rhoref, const TF* rhorefh)
+                 const TF* rhoref, const TF* rhorefh, int cap = 6)   // cap = 4: advec_2i53 (src/advec_2i53.cxx), the same scheme with 4th/3rd order vertically
 {
     const int jj = g.icells, kk = g.ijcells;
     const TF dxi = TF(1.)/TF(g.dx), dyi = TF(1.)/TF(g.dy);
@@ -307,8 +307,8 @@ void advec25_mom(const mhh_grid& g, int comp, TF* t, const TF* u, const TF* v, c
     for (int k=k0; k<g.kend; ++k)
     {
         int ot, ob; TF rt, rb, rc, dz;
-        if (comp == 2) { ot = face_order_w(g, k);   ob = face_order_w(g, k-1); rt = rhoref[k];    rb = rhoref[k-1]; rc = rhorefh[k]; dz = dzhi[k]; }
-        else           { ot = face_order_c(g, k+1); ob = face_order_c(g, k);   rt = rhorefh[k+1]; rb = rhorefh[k];  rc = rhoref[k];  dz = dzi[k];  }
+        if (comp == 2) { ot = std::min(face_order_w(g, k), cap);   ob = std::min(face_order_w(g, k-1), cap); rt = rhoref[k];    rb = rhoref[k-1]; rc = rhorefh[k]; dz = dzhi[k]; }
+        else           { ot = std::min(face_order_c(g, k+1), cap); ob = std::min(face_order_c(g, k), cap);   rt = rhorefh[k+1]; rb = rhorefh[k];  rc = rhoref[k];  dz = dzi[k];  }
         FOR_INTERIOR_PLANE(g)
         {
             const int c = i + j*jj + k*kk;
@@ -322,7 +322,7 @@ void advec25_mom(const mhh_grid& g, int comp, TF* t, const TF* u, const TF* v, c
 
 template<class TF>
 void advec25_s(const mhh_grid& g, TF* t, const TF* s, const TF* u, const TF* v, const TF* w,
-               const TF* rhoref, const TF* rhorefh)
+               const TF* rhoref, const TF* rhorefh, int cap = 6)
 {
     const int jj = g.icells, kk = g.ijcells;
     const TF dxi = TF(1.)/TF(g.dx), dyi = TF(1.)/TF(g.dy);
@@ -343,7 +343,7 @@ void advec25_s(const mhh_grid& g, TF* t, const TF* s, const TF* u, const TF* v, 
         }
     for (int k=g.kstart; k<g.kend; ++k)
     {
-        const int ot = face_order_c(g, k+1), ob = face_order_c(g, k);
+        const int ot = std::min(face_order_c(g, k+1), cap), ob = std::min(face_order_c(g, k), cap);
         FOR_INTERIOR_PLANE(g)
         {
             const int c = i + j*jj + k*kk;
@@ -1498,6 +1498,7 @@ static void advec_mom_t(const mhh_grid& g, int scheme, int comp, void* t, const 
 {
     if (scheme == MHH_ADVEC_2)        advec2_mom<TF>(g, comp, P<TF>(t), P<TF>(u), P<TF>(v), P<TF>(w), P<TF>(r), P<TF>(rh));
     else if (scheme == MHH_ADVEC_2I5) advec25_mom<TF>(g, comp, P<TF>(t), P<TF>(u), P<TF>(v), P<TF>(w), P<TF>(r), P<TF>(rh));
+    else if (scheme == MHH_ADVEC_2I53) advec25_mom<TF>(g, comp, P<TF>(t), P<TF>(u), P<TF>(v), P<TF>(w), P<TF>(r), P<TF>(rh), 4);
     else if (scheme == MHH_ADVEC_2I62) advec262_any<TF>(g, comp, P<TF>(t), comp==0 ? P<TF>(u) : comp==1 ? P<TF>(v) : P<TF>(w), P<TF>(u), P<TF>(v), P<TF>(w), P<TF>(r), P<TF>(rh));
     else if (scheme == MHH_ADVEC_2I4) advec24_any<TF>(g, comp, P<TF>(t), comp==0 ? P<TF>(u) : comp==1 ? P<TF>(v) : P<TF>(w), P<TF>(u), P<TF>(v), P<TF>(w), P<TF>(r), P<TF>(rh));
     else                              advec4_mom<TF>(g, comp, P<TF>(t), P<TF>(u), P<TF>(v), P<TF>(w));
@@ -1514,6 +1515,7 @@ static void advec_s_t(const mhh_grid& g, int scheme, void* t, const void* s, con
 {
     if (scheme == MHH_ADVEC_2)        advec2_s<TF>(g, P<TF>(t), P<TF>(s), P<TF>(u), P<TF>(v), P<TF>(w), P<TF>(r), P<TF>(rh));
     else if (scheme == MHH_ADVEC_2I5) advec25_s<TF>(g, P<TF>(t), P<TF>(s), P<TF>(u), P<TF>(v), P<TF>(w), P<TF>(r), P<TF>(rh));
+    else if (scheme == MHH_ADVEC_2I53) advec25_s<TF>(g, P<TF>(t), P<TF>(s), P<TF>(u), P<TF>(v), P<TF>(w), P<TF>(r), P<TF>(rh), 4);
     else if (scheme == MHH_ADVEC_2I62) advec262_any<TF>(g, 3, P<TF>(t), P<TF>(s), P<TF>(u), P<TF>(v), P<TF>(w), P<TF>(r), P<TF>(rh));
     else if (scheme == MHH_ADVEC_2I4) advec24_any<TF>(g, 3, P<TF>(t), P<TF>(s), P<TF>(u), P<TF>(v), P<TF>(w), P<TF>(r), P<TF>(rh));
     else                              advec4_s<TF>(g, P<TF>(t), P<TF>(s), P<TF>(u), P<TF>(v), P<TF>(w));
