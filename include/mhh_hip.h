@@ -45,6 +45,7 @@ extern "C" {
 /* advection schemes (src/advec.cxx:55-83 swadvec) */
 #define MHH_ADVEC_2    2
 #define MHH_ADVEC_2I5  25
+#define MHH_ADVEC_4M   41   /* 4th-order kinetic-energy-conserving form (src/advec_4m.cxx); per-field entry points only */
 #define MHH_ADVEC_2I53 253  /* advec_2i5 with 4th/3rd instead of 6th/5th order vertically (src/advec_2i53.cxx); per-field entry points only */
 #define MHH_ADVEC_2I62 262  /* 6th-order interpolation horizontally, 2nd order vertically (src/advec_2i62.cxx); per-field entry points only */
 #define MHH_ADVEC_2I4  24   /* 2nd-order fluxes with 4th-order interpolation (src/advec_2i4.cxx); per-field entry points only */
@@ -125,6 +126,7 @@ int mhh_boundary_cyclic_n (const mhh_grid* g, void* const* data, int nfields, in
  * scheme 24 : src/advec_2i4.cxx:101-640 (advec_u/v/w/s), calc_cfl :51-99
  * scheme 262: src/advec_2i62.cxx:105-310,                calc_cfl :58-105
  * scheme 253: src/advec_2i53.cxx:120-700,                calc_cfl :55-118
+ * scheme 41 : src/advec_4m.cxx:90-478,                   calc_cfl :51-88
  * Each call adds the advective tendency of one field (read-modify-write of the tendency). */
 int mhh_advec_u(const mhh_grid* g, int scheme, void* ut, const void* u, const void* v, const void* w,
                 const void* rhoref, const void* rhorefh, void* stream);

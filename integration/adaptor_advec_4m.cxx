@@ -1,0 +1,50 @@
+// integration/adaptor_advec_4m.cxx -- replaces the USECUDA half of the reference's Advec_4m (src/advec_4m.cu).
+#include <algorithm>
+#include "advec_4m.h"
+#include "grid.h"
+#include "fields.h"
+#include "stats.h"
+#include "mhh_adaptor.h"
+
+#ifdef USECUDA
+template<typename TF>
+void Advec_4m<TF>::exec(Stats<TF>& stats)
+{
+    mhh_grid g = mhh_make_grid(grid.get_grid_data(), master.get_MPI_data());
+    mhh_fields f = mhh_make_fields(fields);
+    mhh_check(mhh_advec_exec(&g, MHH_ADVEC_4M, &f, /*stream*/ nullptr));
+    stats.calc_tend(*fields.mt.at("u"), tend_name);
+    stats.calc_tend(*fields.mt.at("v"), tend_name);
+    stats.calc_tend(*fields.mt.at("w"), tend_name);
+    for (auto& it : fields.st)
+        stats.calc_tend(*it.second, tend_name);
+}
+
+template<typename TF>
+double Advec_4m<TF>::get_cfl(const double dt)
+{
+    mhh_grid g = mhh_make_grid(grid.get_grid_data(), master.get_MPI_data());
+    double cfl = 0;
+    auto tmp = fields.get_tmp_g();
+    mhh_check(mhh_advec_cfl(&g, MHH_ADVEC_4M, fields.mp.at("u")->fld_g, fields.mp.at("v")->fld_g, fields.mp.at("w")->fld_g,
+                            dt, tmp->fld_g, &cfl, nullptr));
+    fields.release_tmp_g(tmp);
+    master.max(&cfl, 1);
+    return cfl;
+}
+
+template<typename TF>
+unsigned long Advec_4m<TF>::get_time_limit(unsigned long idt, double dt)
+{
+    double cfl = get_cfl(dt);
+    cfl = std::max(cflmin, cfl);
+    return idt * cflmax / cfl;
+}
+
+template void Advec_4m<double>::exec(Stats<double>&);
+template double Advec_4m<double>::get_cfl(double);
+template unsigned long Advec_4m<double>::get_time_limit(unsigned long, double);
+template void Advec_4m<float>::exec(Stats<float>&);
+template double Advec_4m<float>::get_cfl(double);
+template unsigned long Advec_4m<float>::get_time_limit(unsigned long, double);
+#endif

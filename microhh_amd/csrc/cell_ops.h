@@ -279,6 +279,53 @@ MHH_HD void advec4_mom_v(TF d[3], const FV& f, const UV& u, const VV& v, const W
     d[2] = ( cg0*advec4_pz<COMP,0,TF>(f, w, bot, top) + cg1*advec4_pz<COMP,1,TF>(f, w, bot, top)
            + cg2*advec4_pz<COMP,2,TF>(f, w, bot, top) + cg3*advec4_pz<COMP,3,TF>(f, w, bot, top) ) * dz;
 }
+// advec_4m (src/advec_4m.cxx:90-478): every term is grad4 over four face products, each the 4th-order interpolated
+// advecting velocity times a TWO-point mean of the advected quantity over a widening stencil ((-3,0), (-1,0), (0,1), (0,3)
+// cells along the direction); at the walls the outermost vertical product is the mirrored one. One increment per cell.
+// COMP 0..2 = u, v, w equation, 3 = scalar (velocities taken at their faces, no interpolation).
+template<class TF> MHH_HD TF grad4m(TF a, TF b, TF c, TF d) { return - TF(1./24.)*(d-a) - TF(-27./24.)*(c-b); }
+template<int COMP, int DI, int DJ, int DK, class TF, class V>
+MHH_HD TF vel4m(const V& a)
+{
+    if constexpr (COMP == 3) return a.template at<DI, DJ, DK>();
+    else
+    {   // interp4c, the paired form -1/16 (a+d) + 9/16 (b+c) (advec_4 proper uses the four-term sum)
+        constexpr int EI = (COMP == 0), EJ = (COMP == 1), EK = (COMP == 2);
+        return i4c<TF>(a.template at<DI-2*EI, DJ-2*EJ, DK-2*EK>(), a.template at<DI-EI, DJ-EJ, DK-EK>(),
+                       a.template at<DI, DJ, DK>(), a.template at<DI+EI, DJ+EJ, DK+EK>());
+    }
+}
+template<int COMP, class TF, class FV, class UV, class VV, class WV>
+MHH_HD TF advec4m_v(const FV& f, const UV& u, const VV& v, const WV& w, bool bot, bool top, TF dxi, TF dyi, TF dz)
+{
+    const TF gx = grad4m<TF>(vel4m<COMP,-1,0,0,TF>(u) * i2(f.template at<-3,0,0>(), f.template at<0,0,0>()),
+                             vel4m<COMP, 0,0,0,TF>(u) * i2(f.template at<-1,0,0>(), f.template at<0,0,0>()),
+                             vel4m<COMP, 1,0,0,TF>(u) * i2(f.template at< 0,0,0>(), f.template at<1,0,0>()),
+                             vel4m<COMP, 2,0,0,TF>(u) * i2(f.template at< 0,0,0>(), f.template at<3,0,0>()));
+    const TF gy = grad4m<TF>(vel4m<COMP,0,-1,0,TF>(v) * i2(f.template at<0,-3,0>(), f.template at<0,0,0>()),
+                             vel4m<COMP,0, 0,0,TF>(v) * i2(f.template at<0,-1,0>(), f.template at<0,0,0>()),
+                             vel4m<COMP,0, 1,0,TF>(v) * i2(f.template at<0, 0,0>(), f.template at<0,1,0>()),
+                             vel4m<COMP,0, 2,0,TF>(v) * i2(f.template at<0, 0,0>(), f.template at<0,3,0>()));
+    const TF p0 = bot ? -vel4m<COMP,0,0, 1,TF>(w) * i2(f.template at<0,0,-1>(), f.template at<0,0,2>())
+                      :  vel4m<COMP,0,0,-1,TF>(w) * i2(f.template at<0,0,-3>(), f.template at<0,0,0>());
+    const TF p3 = top ? -vel4m<COMP,0,0, 0,TF>(w) * i2(f.template at<0,0,-2>(), f.template at<0,0,1>())
+                      :  vel4m<COMP,0,0, 2,TF>(w) * i2(f.template at<0,0, 0>(), f.template at<0,0,3>());
+    const TF gz = grad4m<TF>(p0,
+                             vel4m<COMP,0,0,0,TF>(w) * i2(f.template at<0,0,-1>(), f.template at<0,0,0>()),
+                             vel4m<COMP,0,0,1,TF>(w) * i2(f.template at<0,0, 0>(), f.template at<0,0,1>()),
+                             p3);
+    return - gx * dxi - gy * dyi - gz * dz;
+}
+template<class TF>
+MHH_HD TF advec4m(int comp, const TF* __restrict__ f, const TF* __restrict__ u, const TF* __restrict__ v, const TF* __restrict__ w,
+                  int c, int jj, int kk, bool bot, bool top, TF dxi, TF dyi, TF dz)
+{
+    const GlobalView<TF> fv{f, c, jj, kk}, uv{u, c, jj, kk}, vv{v, c, jj, kk}, wv{w, c, jj, kk};
+    if (comp == 0) return advec4m_v<0, TF>(fv, uv, vv, wv, bot, top, dxi, dyi, dz);
+    if (comp == 1) return advec4m_v<1, TF>(fv, uv, vv, wv, bot, top, dxi, dyi, dz);
+    if (comp == 2) return advec4m_v<2, TF>(fv, uv, vv, wv, false, false, dxi, dyi, dz);
+    return advec4m_v<3, TF>(fv, uv, vv, wv, bot, top, dxi, dyi, dz);
+}
 template<class TF>
 MHH_HD void advec4_mom(TF d[3], const TF* __restrict__ f, const TF* __restrict__ u, const TF* __restrict__ v, const TF* __restrict__ w,
                        int c, int sd, bool is_w, int jj, int kk, bool bot, bool top, TF dxi, TF dyi, TF dz, bool dim3)
@@ -318,6 +365,9 @@ MHH_HD TF cfl_cell(int scheme, const TF* __restrict__ u, const TF* __restrict__ 
 {
     if (scheme == 2)
         return tabs(i2(u[c], u[c+1]))*dxi + tabs(i2(v[c], v[c+jj]))*dyi + tabs(i2(w[c], w[c+kk]))*dzi_k;
+    if (scheme == 41)       // src/advec_4m.cxx:51-88: the weighted sum spelled out, metrics dxi = 1./dx and dzi
+        return tabs(ci4(u[c-1], u[c], u[c+1], u[c+2]))*dxi + tabs(ci4(v[c-jj], v[c], v[c+jj], v[c+2*jj]))*dyi
+             + tabs(ci4(w[c-kk], w[c], w[c+kk], w[c+2*kk]))*dzi_k;
     if (scheme == 262)      // src/advec_2i62.cxx:58-105
         return tabs(i6(u[c-2], u[c-1], u[c], u[c+1], u[c+2], u[c+3]))*dxi + tabs(i6(v[c-2*jj], v[c-jj], v[c], v[c+jj], v[c+2*jj], v[c+3*jj]))*dyi
              + tabs(i2(w[c], w[c+kk]))*dzi_k;

@@ -62,7 +62,7 @@ template<class TF> struct CflOp
 MHH_API int mhh_advec_cfl(const mhh_grid* g, int scheme, const void* u, const void* v, const void* w, double dt, void* work, double* cfl_out, void* stream)
 {
     if (int e = check_grid(g)) return e;
-    MHH_REQUIRE(scheme == MHH_ADVEC_2 || scheme == MHH_ADVEC_2I5 || scheme == MHH_ADVEC_4 || scheme == MHH_ADVEC_2I4 || scheme == MHH_ADVEC_2I62 || scheme == MHH_ADVEC_2I53, "scheme");
+    MHH_REQUIRE(scheme == MHH_ADVEC_2 || scheme == MHH_ADVEC_2I5 || scheme == MHH_ADVEC_4 || scheme == MHH_ADVEC_2I4 || scheme == MHH_ADVEC_2I62 || scheme == MHH_ADVEC_2I53 || scheme == MHH_ADVEC_4M, "scheme");
     MHH_REQUIRE(u && v && w, "null field");
     double m = 0; int e;
     if (g->dtype == MHH_F64) { CflOp<double> op{make_grid<double>(g), scheme, cp<double>(u), cp<double>(v), cp<double>(w)}; e = reduce_max<double>(g, op, work, &m, as_stream(stream)); if (!e) *cfl_out = m*dt; }

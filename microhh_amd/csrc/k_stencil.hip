@@ -123,6 +123,12 @@ struct AdvecOp
     {
         const int jj = g.icells, kk = g.ijcells;
         const bool isw = (comp == 2);
+        if (scheme == MHH_ADVEC_4M)
+        {
+            const bool bot = (k == g.kstart), top = (k == g.kend-1);
+            t[c] += advec4m(comp, f, u, v, w, c, jj, kk, bot, top, g.dxi_d, g.dyi_d, isw ? g.dzhi4[k] : g.dzi4[k]);
+            return;
+        }
         if (scheme == MHH_ADVEC_4)
         {
             const int k0 = isw ? g.kstart+1 : g.kstart;
@@ -185,7 +191,8 @@ struct AdvecOp
 static int check_advec(const mhh_grid* g, int scheme)
 {
     if (int e = check_grid(g)) return e;
-    MHH_REQUIRE(scheme == MHH_ADVEC_2 || scheme == MHH_ADVEC_2I5 || scheme == MHH_ADVEC_4 || scheme == MHH_ADVEC_2I4 || scheme == MHH_ADVEC_2I62 || scheme == MHH_ADVEC_2I53, "scheme must be 2, 24, 25, 253, 262 or 4");
+    MHH_REQUIRE(scheme == MHH_ADVEC_2 || scheme == MHH_ADVEC_2I5 || scheme == MHH_ADVEC_4 || scheme == MHH_ADVEC_2I4 || scheme == MHH_ADVEC_2I62 || scheme == MHH_ADVEC_2I53 || scheme == MHH_ADVEC_4M, "scheme must be 2, 24, 25, 253, 262, 4 or 41");
+    if (scheme == MHH_ADVEC_4M) MHH_REQUIRE(g->igc >= 3 && g->jgc >= 3 && g->kgc >= 3 && g->ktot >= 2, "advec_4m needs gc(3,3,3)");
     if (scheme == MHH_ADVEC_2I53) MHH_REQUIRE(g->igc >= 3 && g->jgc >= 3 && g->kgc >= 1 && g->ktot >= 4, "advec_2i53 needs gc(3,3,1), ktot >= 4");
     if (scheme == MHH_ADVEC_2I62) MHH_REQUIRE(g->igc >= 3 && g->jgc >= 3 && g->kgc >= 1, "advec_2i62 needs gc(3,3,1) (src/advec_2i62.cxx:42-45)");
     if (scheme == MHH_ADVEC_2I4) MHH_REQUIRE(g->igc >= 2 && g->jgc >= 2 && g->kgc >= 1 && g->ktot >= 4, "advec_2i4 needs gc(2,2,1) and ktot >= 4 (the reference asks for gc(2,2,2), src/advec_2i4.cxx:38-41)");
@@ -207,7 +214,7 @@ static int advec_any(const mhh_grid* g, int scheme, int comp, void* t, const voi
 {
     if (int e = check_advec(g, scheme)) return e;
     MHH_REQUIRE(t && f && u && v && w, "null field");
-    MHH_REQUIRE(scheme == MHH_ADVEC_4 || (r && rh), "rhoref/rhorefh required");
+    MHH_REQUIRE(scheme == MHH_ADVEC_4 || scheme == MHH_ADVEC_4M || (r && rh), "rhoref/rhorefh required");
     if (g->dtype == MHH_F64) return advec_launch<double>(g, scheme, comp, t, f, u, v, w, r, rh, stream);
     return advec_launch<float>(g, scheme, comp, t, f, u, v, w, r, rh, stream);
 }

@@ -13,7 +13,7 @@ import numpy as np
 MHH_F64, MHH_F32 = 0, 1
 EDGE_EW, EDGE_NS, EDGE_BOTH = 0, 1, 2
 ADVEC_2, ADVEC_2I5, ADVEC_4 = 2, 25, 4
-ADVEC_2I4, ADVEC_2I62, ADVEC_2I53 = 24, 262, 253
+ADVEC_2I4, ADVEC_2I62, ADVEC_2I53, ADVEC_4M = 24, 262, 253, 41
 DIFF_2, DIFF_4, DIFF_SMAG2 = 2, 4, 22
 MAX_SCALARS = 8
 

@@ -230,7 +230,7 @@ class Advec
         {
             int s;
             if (swadvec == "2") s = MHH_ADVEC_2; else if (swadvec == "2i5") s = MHH_ADVEC_2I5; else if (swadvec == "4") s = MHH_ADVEC_4;
-            else if (swadvec == "2i4") s = MHH_ADVEC_2I4; else if (swadvec == "2i62") s = MHH_ADVEC_2I62; else if (swadvec == "2i53") s = MHH_ADVEC_2I53;
+            else if (swadvec == "2i4") s = MHH_ADVEC_2I4; else if (swadvec == "2i62") s = MHH_ADVEC_2I62; else if (swadvec == "2i53") s = MHH_ADVEC_2I53; else if (swadvec == "4m") s = MHH_ADVEC_4M;
             else throw std::runtime_error("\"" + swadvec + "\" is an illegal value for swadvec");
             return std::make_shared<Advec>(g, f, s, cflmax, std::move(fluxlimit_list));
         }

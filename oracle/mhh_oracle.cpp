@@ -195,6 +195,10 @@ double advec_cfl(const mhh_grid& g, int scheme, const TF* u, const TF* v, const 
             TF a;
             if (scheme == MHH_ADVEC_2)
                 a = std::abs(i2(u[c], u[c+1]))*dxi + std::abs(i2(v[c], v[c+jj]))*dyi + std::abs(i2(w[c], w[c+kk]))*dzi[k];
+            else if (scheme == MHH_ADVEC_4M)                        // src/advec_4m.cxx:51-88
+                a = std::abs(TF(-1./16.)*u[c-1] + TF(9./16.)*u[c] + TF(9./16.)*u[c+1] + TF(-1./16.)*u[c+2])*dxi
+                  + std::abs(TF(-1./16.)*v[c-jj] + TF(9./16.)*v[c] + TF(9./16.)*v[c+jj] + TF(-1./16.)*v[c+2*jj])*dyi
+                  + std::abs(TF(-1./16.)*w[c-kk] + TF(9./16.)*w[c] + TF(9./16.)*w[c+kk] + TF(-1./16.)*w[c+2*kk])*dzi[k];
             else if (scheme == MHH_ADVEC_2I62)                      // src/advec_2i62.cxx:58-105
                 a = std::abs(i6(u[c-2], u[c-1], u[c], u[c+1], u[c+2], u[c+3]))*dxi
                   + std::abs(i6(v[c-2*jj], v[c-jj], v[c], v[c+jj], v[c+2*jj], v[c+3*jj]))*dyi
@@ -1493,12 +1497,55 @@ void advec262_any(const mhh_grid& g, int comp, TF* t, const TF* f, const TF* u, 
 }
 }
 
+namespace {
+// advec_4m (src/advec_4m.cxx:90-478). For each direction: four face products P_m = V_m * mean(f[lo_m], f[hi_m]) with
+// (lo, hi) = (-3,0), (-1,0), (0,1), (0,3) cells and V_m the advecting velocity at face m-1 (4th-order interpolated along
+// the staggering direction of the equation; taken as is for scalars); the term is -(1/24)(P3-P0) + (27/24)(P2-P1) times
+// the metric. Walls (u, v, scalars): the bottom row replaces P0 by -V(+1) * mean(f[-1], f[+2]), the top row P3 by
+// -V(0) * mean(f[-2], f[+1]).
+template<class TF>
+void advec4m_any(const mhh_grid& g, int comp, TF* t, const TF* f, const TF* u, const TF* v, const TF* w)
+{
+    const int jj = g.icells, kk = g.ijcells;
+    const TF dxi = TF(1./TF(g.dx)), dyi = TF(1./TF(g.dy));
+    const TF* dzi4 = P<TF>(g.dzi4); const TF* dzhi4 = P<TF>(g.dzhi4);
+    const int se = (comp==0) ? 1 : (comp==1) ? jj : (comp==2) ? kk : 0;     // staggering stride of the equation
+    const int lo[4] = {-3, -1, 0, 0}, hi[4] = {0, 0, 1, 3};
+    auto vel = [&](const TF* a, int at) -> TF      // advecting velocity component a at cell offset `at`
+    {
+        if (comp == 3) return a[at];
+        return TF(-1./16.)*(a[at-2*se] + a[at+se]) + TF(9./16.)*(a[at-se] + a[at]);      // interp4c: the paired form
+    };
+    auto grad = [](TF a, TF b, TF c, TF d) -> TF { return - TF(1./24.)*(d-a) - TF(-27./24.)*(c-b); };
+    for (int k=(comp==2 ? g.kstart+1 : g.kstart); k<g.kend; ++k)
+    {
+        const bool bot = (comp != 2) && (k == g.kstart), top = (comp != 2) && (k == g.kend-1);
+        const TF dz = (comp==2) ? dzhi4[k] : dzi4[k];
+        FOR_INTERIOR_PLANE(g)
+        {
+            const int c = i + j*jj + k*kk;
+            TF px[4], py[4], pz[4];
+            for (int m=0; m<4; ++m)
+            {
+                px[m] = vel(u, c + (m-1))    * (TF(0.5)*(f[c+lo[m]]    + f[c+hi[m]]));
+                py[m] = vel(v, c + (m-1)*jj) * (TF(0.5)*(f[c+lo[m]*jj] + f[c+hi[m]*jj]));
+                pz[m] = vel(w, c + (m-1)*kk) * (TF(0.5)*(f[c+lo[m]*kk] + f[c+hi[m]*kk]));
+            }
+            if (bot) pz[0] = -vel(w, c + kk) * (TF(0.5)*(f[c-kk]   + f[c+2*kk]));
+            if (top) pz[3] = -vel(w, c)      * (TF(0.5)*(f[c-2*kk] + f[c+kk]));
+            t[c] += - grad(px[0], px[1], px[2], px[3]) * dxi - grad(py[0], py[1], py[2], py[3]) * dyi - grad(pz[0], pz[1], pz[2], pz[3]) * dz;
+        }
+    }
+}
+}
+
 template<class TF>
 static void advec_mom_t(const mhh_grid& g, int scheme, int comp, void* t, const void* u, const void* v, const void* w, const void* r, const void* rh)
 {
     if (scheme == MHH_ADVEC_2)        advec2_mom<TF>(g, comp, P<TF>(t), P<TF>(u), P<TF>(v), P<TF>(w), P<TF>(r), P<TF>(rh));
     else if (scheme == MHH_ADVEC_2I5) advec25_mom<TF>(g, comp, P<TF>(t), P<TF>(u), P<TF>(v), P<TF>(w), P<TF>(r), P<TF>(rh));
     else if (scheme == MHH_ADVEC_2I53) advec25_mom<TF>(g, comp, P<TF>(t), P<TF>(u), P<TF>(v), P<TF>(w), P<TF>(r), P<TF>(rh), 4);
+    else if (scheme == MHH_ADVEC_4M) advec4m_any<TF>(g, comp, P<TF>(t), comp==0 ? P<TF>(u) : comp==1 ? P<TF>(v) : P<TF>(w), P<TF>(u), P<TF>(v), P<TF>(w));
     else if (scheme == MHH_ADVEC_2I62) advec262_any<TF>(g, comp, P<TF>(t), comp==0 ? P<TF>(u) : comp==1 ? P<TF>(v) : P<TF>(w), P<TF>(u), P<TF>(v), P<TF>(w), P<TF>(r), P<TF>(rh));
     else if (scheme == MHH_ADVEC_2I4) advec24_any<TF>(g, comp, P<TF>(t), comp==0 ? P<TF>(u) : comp==1 ? P<TF>(v) : P<TF>(w), P<TF>(u), P<TF>(v), P<TF>(w), P<TF>(r), P<TF>(rh));
     else                              advec4_mom<TF>(g, comp, P<TF>(t), P<TF>(u), P<TF>(v), P<TF>(w));
@@ -1516,6 +1563,7 @@ static void advec_s_t(const mhh_grid& g, int scheme, void* t, const void* s, con
     if (scheme == MHH_ADVEC_2)        advec2_s<TF>(g, P<TF>(t), P<TF>(s), P<TF>(u), P<TF>(v), P<TF>(w), P<TF>(r), P<TF>(rh));
     else if (scheme == MHH_ADVEC_2I5) advec25_s<TF>(g, P<TF>(t), P<TF>(s), P<TF>(u), P<TF>(v), P<TF>(w), P<TF>(r), P<TF>(rh));
     else if (scheme == MHH_ADVEC_2I53) advec25_s<TF>(g, P<TF>(t), P<TF>(s), P<TF>(u), P<TF>(v), P<TF>(w), P<TF>(r), P<TF>(rh), 4);
+    else if (scheme == MHH_ADVEC_4M) advec4m_any<TF>(g, 3, P<TF>(t), P<TF>(s), P<TF>(u), P<TF>(v), P<TF>(w));
     else if (scheme == MHH_ADVEC_2I62) advec262_any<TF>(g, 3, P<TF>(t), P<TF>(s), P<TF>(u), P<TF>(v), P<TF>(w), P<TF>(r), P<TF>(rh));
     else if (scheme == MHH_ADVEC_2I4) advec24_any<TF>(g, 3, P<TF>(t), P<TF>(s), P<TF>(u), P<TF>(v), P<TF>(w), P<TF>(r), P<TF>(rh));
     else                              advec4_s<TF>(g, P<TF>(t), P<TF>(s), P<TF>(u), P<TF>(v), P<TF>(w));

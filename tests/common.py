@@ -15,7 +15,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from microhh_amd.grid import (Grid, MhhGrid, EDGE_EW, EDGE_NS, EDGE_BOTH,  # noqa: E402,F401
-                              ADVEC_2, ADVEC_2I5, ADVEC_2I4, ADVEC_2I62, ADVEC_2I53, ADVEC_4, DIFF_2, DIFF_4, DIFF_SMAG2, moser_z, uniform_z)
+                              ADVEC_2, ADVEC_2I5, ADVEC_2I4, ADVEC_2I62, ADVEC_2I53, ADVEC_4M, ADVEC_4, DIFF_2, DIFF_4, DIFF_SMAG2, moser_z, uniform_z)
 
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 _libs = {}
@@ -51,7 +51,7 @@ def ref(perf=False):
         else:
             return None
     lib = _load(p)
-    for n in ("ref_advec_2_cfl", "ref_advec_2i5_cfl", "ref_advec_2i4_cfl", "ref_advec_2i62_cfl", "ref_advec_2i53_cfl", "ref_advec_4_cfl", "ref_smag2_dnmul"):
+    for n in ("ref_advec_2_cfl", "ref_advec_2i5_cfl", "ref_advec_2i4_cfl", "ref_advec_2i62_cfl", "ref_advec_2i53_cfl", "ref_advec_4m_cfl", "ref_advec_4_cfl", "ref_smag2_dnmul"):
         getattr(lib, n).restype = C.c_double
     return lib
 

@@ -32,7 +32,7 @@ def main():
     assert R is not None, "needs /root/reference (oracle/_ref)"
     g2, c2, g4, c4 = cases()
     out = {}
-    for scheme, name, g, c in ((2, "ref_advec_2", g2, c2), (25, "ref_advec_2i5", g2, c2), (24, "ref_advec_2i4", g2, c2), (262, "ref_advec_2i62", g2, c2), (253, "ref_advec_2i53", g2, c2), (4, "ref_advec_4", g4, c4)):
+    for scheme, name, g, c in ((2, "ref_advec_2", g2, c2), (25, "ref_advec_2i5", g2, c2), (24, "ref_advec_2i4", g2, c2), (262, "ref_advec_2i62", g2, c2), (253, "ref_advec_2i53", g2, c2), (4, "ref_advec_4", g4, c4), (41, "ref_advec_4m", g4, c4)):
         G = g.host_struct()
         for comp, tn in enumerate(("ut", "vt", "wt")):
             t = c.copy_of(tn)

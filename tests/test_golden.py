@@ -26,7 +26,7 @@ def test_input_recipe_unchanged():
 def test_oracle_reproduces_reference_vectors():
     O = cm.oracle()
     g2, c2, g4, c4 = mg.cases()
-    for scheme, g, c in ((2, g2, c2), (25, g2, c2), (24, g2, c2), (262, g2, c2), (253, g2, c2), (4, g4, c4)):
+    for scheme, g, c in ((2, g2, c2), (25, g2, c2), (24, g2, c2), (262, g2, c2), (253, g2, c2), (4, g4, c4), (41, g4, c4)):
         G = g.host_struct()
         for fn, tn in ((O.orc_advec_u, "ut"), (O.orc_advec_v, "vt"), (O.orc_advec_w, "wt")):
             t = c.copy_of(tn); fn(G, scheme, ptr(t), ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.rhoref), ptr(c.rhorefh))
@@ -61,7 +61,7 @@ def test_oracle_reproduces_reference_vectors():
 def test_hip_path_reproduces_reference_vectors(name):
     be = B.get(name)
     g2, c2, g4, c4 = mg.cases()
-    for scheme, g, c in ((2, g2, c2), (25, g2, c2), (24, g2, c2), (262, g2, c2), (253, g2, c2), (4, g4, c4)):
+    for scheme, g, c in ((2, g2, c2), (25, g2, c2), (24, g2, c2), (262, g2, c2), (253, g2, c2), (4, g4, c4), (41, g4, c4)):
         d = B.DevCase(be, c)
         for fn, tn in ((be.lib.mhh_advec_u, "ut"), (be.lib.mhh_advec_v, "vt"), (be.lib.mhh_advec_w, "wt")):
             t = be.arr(getattr(c, tn))

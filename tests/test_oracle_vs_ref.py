@@ -25,10 +25,10 @@ def grids4(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("scheme,refname", [(cm.ADVEC_2, "ref_advec_2"), (cm.ADVEC_2I5, "ref_advec_2i5"), (cm.ADVEC_2I4, "ref_advec_2i4"), (cm.ADVEC_2I62, "ref_advec_2i62"), (cm.ADVEC_2I53, "ref_advec_2i53"), (cm.ADVEC_4, "ref_advec_4")])
+@pytest.mark.parametrize("scheme,refname", [(cm.ADVEC_2, "ref_advec_2"), (cm.ADVEC_2I5, "ref_advec_2i5"), (cm.ADVEC_2I4, "ref_advec_2i4"), (cm.ADVEC_2I62, "ref_advec_2i62"), (cm.ADVEC_2I53, "ref_advec_2i53"), (cm.ADVEC_4, "ref_advec_4"), (cm.ADVEC_4M, "ref_advec_4m")])
 def test_advec_bitwise(scheme, refname, dtype):
     O = cm.oracle()
-    for g in (grids4(dtype) if scheme == cm.ADVEC_4 else grids2(dtype)):
+    for g in (grids4(dtype) if scheme in (cm.ADVEC_4, cm.ADVEC_4M) else grids2(dtype)):
         if scheme == cm.ADVEC_2I5 and g.ktot < 6:
             continue
         if scheme in (cm.ADVEC_2I4, cm.ADVEC_2I53) and (g.igc < 2 or g.jgc < 2 or g.ktot < 4):

@@ -97,10 +97,10 @@ def test_advec_s_lim_bitexact(be, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("scheme", [cm.ADVEC_2, cm.ADVEC_2I5, cm.ADVEC_2I4, cm.ADVEC_2I62, cm.ADVEC_2I53, cm.ADVEC_4])
+@pytest.mark.parametrize("scheme", [cm.ADVEC_2, cm.ADVEC_2I5, cm.ADVEC_2I4, cm.ADVEC_2I62, cm.ADVEC_2I53, cm.ADVEC_4, cm.ADVEC_4M])
 def test_advec_kernels_bitexact(be, scheme, dtype):
     O = cm.oracle()
-    for g in (grids4(dtype) if scheme == cm.ADVEC_4 else grids2(dtype)):
+    for g in (grids4(dtype) if scheme in (cm.ADVEC_4, cm.ADVEC_4M) else grids2(dtype)):
         if scheme in (cm.ADVEC_2I4, cm.ADVEC_2I53) and (g.igc < 2 or g.jgc < 2 or g.ktot < 4):
             continue
         c = cm.Case(g); d = B.DevCase(be, c); Gh = g.host_struct()
