@@ -229,7 +229,8 @@ class Advec
                                               std::vector<std::string> fluxlimit_list = {})
         {
             int s;
-            if (swadvec == "2") s = MHH_ADVEC_2; else if (swadvec == "2i5") s = MHH_ADVEC_2I5; else if (swadvec == "4") s = MHH_ADVEC_4;
+            if (swadvec == "0") s = 0;                 // Advec_disabled (src/advec_disabled.cxx)
+            else if (swadvec == "2") s = MHH_ADVEC_2; else if (swadvec == "2i5") s = MHH_ADVEC_2I5; else if (swadvec == "4") s = MHH_ADVEC_4;
             else if (swadvec == "2i4") s = MHH_ADVEC_2I4; else if (swadvec == "2i62") s = MHH_ADVEC_2I62; else if (swadvec == "2i53") s = MHH_ADVEC_2I53; else if (swadvec == "4m") s = MHH_ADVEC_4M;
             else throw std::runtime_error("\"" + swadvec + "\" is an illegal value for swadvec");
             return std::make_shared<Advec>(g, f, s, cflmax, std::move(fluxlimit_list));
@@ -238,6 +239,7 @@ class Advec
         void create(Stats&) {}
         void exec(Stats&, void* stream = nullptr)
         {
+            if (scheme == 0) return;
             mhh_grid g = grid.abi(); mhh_fields f = abi_fields(fields); mark_limited(f);
             mhh_check(mhh_advec_exec(&g, scheme, &f, stream));
         }
@@ -255,12 +257,14 @@ class Advec
         std::vector<std::string> fluxlimit_list;
         double get_cfl(double dt, void* stream = nullptr)
         {
+            if (scheme == 0) return cflmin;
             mhh_grid g = grid.abi(); double cfl = 0;
             mhh_check(mhh_advec_cfl(&g, scheme, fields.mp.at("u")->fld_g, fields.mp.at("v")->fld_g, fields.mp.at("w")->fld_g, dt, work, &cfl, stream));
             return cfl;
         }
         unsigned long get_time_limit(unsigned long idt, double dt, void* stream = nullptr)
         {
+            if (scheme == 0) return ~0ul;              // Constants::ulhuge
             double cfl = get_cfl(dt, stream);
             cfl = std::max(cflmin, cfl);
             return idt * cflmax / cfl;
@@ -280,7 +284,8 @@ class Diff
         static std::shared_ptr<Diff> factory(Grid<TF>& g, Fields<TF>& f, Boundary<TF>& b, const std::string& swdiff, double dnmax = 0.4, TF cs = 0.23, TF tPr = 1./3.)
         {
             int s;
-            if (swdiff == "2") s = MHH_DIFF_2; else if (swdiff == "4") s = MHH_DIFF_4; else if (swdiff == "smag2") s = MHH_DIFF_SMAG2;
+            if (swdiff == "0") s = 0;                  // Diff_disabled (src/diff_disabled.cxx)
+            else if (swdiff == "2") s = MHH_DIFF_2; else if (swdiff == "4") s = MHH_DIFF_4; else if (swdiff == "smag2") s = MHH_DIFF_SMAG2;
             else throw std::runtime_error("\"" + swdiff + "\" is an illegal value for swdiff");
             return std::make_shared<Diff>(g, f, b, s, dnmax, cs, tPr);
         }
@@ -317,6 +322,7 @@ class Diff
         }
         void exec(Stats&, void* stream = nullptr)
         {
+            if (scheme == 0) return;
             mhh_grid g = grid.abi(); mhh_fields f = abi_fields(fields, &boundary); mhh_diff_params p = params(nullptr);
             mhh_check(mhh_diff_exec(&g, scheme, &f, &p, stream));
         }
@@ -346,6 +352,7 @@ class Diff
         }
         double get_dn(double dt, void* stream = nullptr)
         {
+            if (scheme == 0) return 1.e-9;                // Constants::dsmall (src/diff_disabled.cxx:56-60)
             if (scheme != MHH_DIFF_SMAG2) return dnmul*dt;
             mhh_grid g = grid.abi(); double d = 0;
             mhh_check(mhh_smag2_dnmul(&g, fields.sd.at("evisc")->fld_g, tPr, work, &d, stream));
@@ -353,6 +360,7 @@ class Diff
         }
         unsigned long get_time_limit(unsigned long idt, double dt, void* stream = nullptr)
         {
+            if (scheme == 0) return ~0ul;                 // Constants::ulhuge
             if (scheme != MHH_DIFF_SMAG2) return idt * dnmax / (dt * dnmul);
             mhh_grid g = grid.abi(); double d = 0;
             mhh_check(mhh_smag2_dnmul(&g, fields.sd.at("evisc")->fld_g, tPr, work, &d, stream));
