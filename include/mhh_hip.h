@@ -227,7 +227,8 @@ int mhh_thermo_dry_buoyancy_tend(const mhh_grid* g, int order, void* wt, const v
 /* ---- Fused RHS: advec.exec + diff.exec in one pass over the tendencies ------------------
  * Same arithmetic, same order of accumulation into each tendency as calling
  * mhh_advec_exec then mhh_diff_exec (bit-identical results), one read of every input
- * and one read-modify-write of every tendency. Supported pairs: (2,2) (25,22) (4,4).    */
+ * and one read-modify-write of every tendency for the pairs (2,2) (25,22) (4,4); any other
+ * pair of valid schemes runs as the two operator calls.                                   */
 int mhh_rhs_exec(const mhh_grid* g, int advec_scheme, int diff_scheme, const mhh_fields* f,
                  const mhh_diff_params* p, void* stream);
 

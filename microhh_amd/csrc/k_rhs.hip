@@ -485,8 +485,11 @@ MHH_API int mhh_rhs_exec(const mhh_grid* g, int advec_scheme, int diff_scheme, c
         return MHH_DISPATCH(g, CALL);
 #undef CALL
     }
-    set_error("mhh_rhs_exec: unsupported scheme pair (%d,%d); supported: (2,2) (25,22) (4,4)", advec_scheme, diff_scheme);
-    return MHH_EINVAL;
+    // any other pair of valid schemes: the two operator calls, in the reference's order (same bits as calling them directly)
+    if (p && p->buoyancy)
+        if (int e = mhh_thermo_dry_buoyancy_tend(g, p->buoyancy, f->wt, f->s[p->th_for_N2], p->threfh, p->grav, stream)) return e;
+    if (int e = mhh_advec_exec(g, advec_scheme, f, stream)) return e;
+    return mhh_diff_exec(g, diff_scheme, f, p, stream);
 }
 
 // The (advec_2i5, diff_smag2) pass over the rows [j0, j1) only: the slab driver updates the rows that need no

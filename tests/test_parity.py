@@ -365,6 +365,36 @@ def test_pres_exec_callback_fused_equals_staged(be, order, dtype):
         assert not np.array_equal(out["fused"][0], c.p)
 
 
+@pytest.mark.parametrize("adv,dif", [(cm.ADVEC_2I4, cm.DIFF_2), (cm.ADVEC_2I62, cm.DIFF_SMAG2), (cm.ADVEC_2I53, cm.DIFF_SMAG2), (cm.ADVEC_4M, cm.DIFF_4)])
+def test_rhs_exec_other_scheme_pairs_run_as_two_calls(be, adv, dif):
+    """mhh_rhs_exec accepts every pair of valid schemes: pairs without a fused kernel run Advec::exec then Diff::exec."""
+    O = cm.oracle()
+    g = cm.grid_4th(16, 12, 12) if adv == cm.ADVEC_4M else cm.grid_2nd(16, 12, 10, gc=(3, 3, 2))
+    c = cm.Case(g, nscalars=1); Gh = g.host_struct()
+    sm = 1 if dif == cm.DIFF_SMAG2 else 0
+    ut, vt, wt, st = c.ut.copy(), c.vt.copy(), c.wt.copy(), c.st[0].copy()
+    a = (ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.rhoref), ptr(c.rhorefh))
+    O.orc_advec_u(Gh, adv, ptr(ut), *a); O.orc_advec_v(Gh, adv, ptr(vt), *a); O.orc_advec_w(Gh, adv, ptr(wt), *a); O.orc_advec_s(Gh, adv, ptr(st), ptr(c.s[0]), *a)
+    cpy = cm.Case(g, nscalars=1)
+    cpy.ut, cpy.vt, cpy.wt, cpy.st = ut, vt, wt, [st]
+    want = None
+    if dif == cm.DIFF_SMAG2:
+        O.orc_smag2_diff_u(Gh, sm, ptr(ut), ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.evisc), ptr(c.u_fluxbot), ptr(c.u_fluxtop), ptr(c.rhoref), ptr(c.rhorefh), dbl(1e-5))
+        O.orc_smag2_diff_v(Gh, sm, ptr(vt), ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.evisc), ptr(c.v_fluxbot), ptr(c.v_fluxtop), ptr(c.rhoref), ptr(c.rhorefh), dbl(1e-5))
+        O.orc_smag2_diff_w(Gh, ptr(wt), ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.evisc), ptr(c.rhoref), ptr(c.rhorefh), dbl(1e-5))
+        O.orc_smag2_diff_c(Gh, sm, ptr(st), ptr(c.s[0]), ptr(c.evisc), ptr(c.s_fluxbot), ptr(c.s_fluxtop), ptr(c.rhoref), ptr(c.rhorefh), dbl(1./3.), dbl(1e-5))
+    else:
+        o = 2 if dif == cm.DIFF_2 else 4
+        O.orc_diff_c(Gh, o, ptr(ut), ptr(c.u), dbl(1e-5)); O.orc_diff_c(Gh, o, ptr(vt), ptr(c.v), dbl(1e-5)); O.orc_diff_w(Gh, o, ptr(wt), ptr(c.w), dbl(1e-5))
+        O.orc_diff_c(Gh, o, ptr(st), ptr(c.s[0]), dbl(1e-5))
+    d = B.DevCase(be, c); f = d.fields()
+    p = capi.MhhDiffParams(); p.cs = 0.23; p.tPr = 1./3.; p.surface_model = sm
+    B.ok(be, be.lib.mhh_rhs_exec(d.G, adv, dif, C.byref(f), C.byref(p), be.stream))
+    for got, w_, nm in ((d.ut, ut, "ut"), (d.vt, vt, "vt"), (d.wt, wt, "wt"), (d.st[0], st, "st")):
+        assert same(be.host(got), w_), (adv, dif, nm)
+    assert be.lib.mhh_rhs_exec(d.G, 7, dif, C.byref(f), C.byref(p), be.stream) != 0
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_fused_rhs_on_minimal_and_ragged_grids(be, dtype):
     """Smallest legal vertical extent (every level is wall-adjacent: no interior fast path), tiles narrower than a wave,
