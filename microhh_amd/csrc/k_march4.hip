@@ -158,10 +158,13 @@ __global__ void __launch_bounds__(64*NJ, MHH_MARCH4_OCC) rhs44_march_kernel(cons
     if (c_pending >= 0) { f.ut[c_pending] = ut_pending; f.vt[c_pending] = vt_pending; }
 }
 
+#ifndef MHH_MARCH4_NJ
+#define MHH_MARCH4_NJ 4
+#endif
 template<class TF>
 int march4_launch(const mhh_grid* g, const mhh_fields* f, int pb, hipStream_t st)
 {
-    constexpr int NJ = 4;
+    constexpr int NJ = MHH_MARCH4_NJ;
     March4Fields<TF> mf;
     mf.u = cp<TF>(f->u); mf.v = cp<TF>(f->v); mf.w = cp<TF>(f->w);
     mf.ut = mp<TF>(f->ut); mf.vt = mp<TF>(f->vt); mf.wt = mp<TF>(f->wt); mf.visc = TF(f->visc);
