@@ -478,14 +478,23 @@ __global__ void __launch_bounds__(128) hdma_solve_kernel(TF* __restrict__ p, con
 // unpack (src/pres_2.cxx:333-362, src/pres_4.cxx:481-528): normalise, ghosted layout, vertical ghost rows,
 // periodic halo -- one kernel over icells x jcells x (kmax + vertical ghosts), reading with wrapped indices.
 // =======================================================================================================
-template<class TF>
+// The transform's normalisation, value / jtot / itot (src/fft.cxx). Where both extents are powers of two (POW2) the two
+// divisions are two multiplications by the exact reciprocals: the same correctly rounded results, a tenth of the issue slots.
+template<bool POW2, class TF>
+__device__ __forceinline__ TF fft_norm(TF v, int itot, int jtot, TF ri, TF rj) { return POW2 ? (v * rj) * ri : v / jtot / itot; }
+static inline bool is_pow2(int n) { return n > 0 && (n & (n-1)) == 0; }
+
+// Threads run over the flattened (i, j) plane of the ghosted layout (rows of icells are contiguous, so a wave still stores
+// one contiguous run): no thread of a block is idle whatever icells is.
+template<bool POW2, class TF>
 __global__ void __launch_bounds__(256) unpack_kernel(TF* __restrict__ p, const TF* __restrict__ packed, int order,
                                                      int itot, int jtot, int kmax, int igc, int jgc, int kgc, int icells, int jcells)
 {
-    const int i = blockIdx.x*256 + threadIdx.x;
-    const int j = blockIdx.y;
+    const int ijc = blockIdx.x*256 + threadIdx.x;
     const int kz = blockIdx.z;                 // 0 .. kmax-1 + nghost rows
-    if (i >= icells) return;
+    if (ijc >= icells*jcells) return;
+    const int j = ijc / icells, i = ijc - j*icells;
+    const TF ri = TF(1)/TF(itot), rj = TF(1)/TF(jtot);
     // destination level and source level
     int kd, ks;
     if (kz < kmax) { kd = kz + kgc; ks = kz; }
@@ -500,8 +509,8 @@ __global__ void __launch_bounds__(256) unpack_kernel(TF* __restrict__ p, const T
     }
     int is = (i - igc) % itot; if (is < 0) is += itot;
     int js = (j - jgc) % jtot; if (js < 0) js += jtot;
-    const TF val = packed[(size_t)is + (size_t)js*itot + (size_t)ks*itot*jtot] / jtot / itot;
-    p[(size_t)i + (size_t)j*icells + (size_t)kd*icells*jcells] = val;
+    const TF val = fft_norm<POW2>(packed[(size_t)is + (size_t)js*itot + (size_t)ks*itot*jtot], itot, jtot, ri, rj);
+    p[(size_t)ijc + (size_t)kd*icells*jcells] = val;
 }
 
 // the k-sweep per (kx, ky) column between the two transforms: Thomas (pres_2) or the factored 7-band substitution (pres_4)
@@ -528,13 +537,43 @@ static int pres_column_solve(mhh_pres_plan* P, const mhh_grid* g, hipStream_t st
     return MHH_OK;
 }
 
-MHH_API int mhh_pres_solve(mhh_pres_plan* P, const mhh_grid* g, const mhh_fields* f, void* p_packed, void* stream)
+// unpack and Pres_2::output in one pass (src/pres_2.cxx:333-387): every thread normalises and stores its own p (interior,
+// halo or bottom ghost row, as unpack_kernel) and, on interior cells, also the three neighbours the pressure gradient
+// needs -- re-normalised from the packed solution with the same two divisions, so that the values are the stored ones --
+// and corrects ut, vt, wt. One read of p less, one kernel less than unpack + output.
+template<bool POW2, class TF>
+__global__ void __launch_bounds__(256) unpack_out2_kernel(TF* __restrict__ p, const TF* __restrict__ packed,
+                                                          TF* __restrict__ ut, TF* __restrict__ vt, TF* __restrict__ wt, const TF* __restrict__ dzhi,
+                                                          TF dxi, TF dyi, int itot, int jtot, int kmax, int igc, int jgc, int kgc, int icells, int jcells)
 {
-    if (int e = check_grid(g)) return e;
-    MHH_REQUIRE(P && f && f->p, "null field");
-    MHH_REQUIRE(P->dtype == g->dtype && P->itot == g->itot && P->jtot == g->jtot && P->ktot == g->ktot, "plan/grid mismatch");
-    if (!p_packed) p_packed = P->packed;
-    hipStream_t st = as_stream(stream);
+    const int ijc = blockIdx.x*256 + threadIdx.x;
+    const int kz = blockIdx.z;                 // 0 .. kmax-1, kmax = the bottom ghost row
+    if (ijc >= icells*jcells) return;
+    const int j = ijc / icells, i = ijc - j*icells;
+    const TF ri = TF(1)/TF(itot), rj = TF(1)/TF(jtot);
+    const int kd = (kz < kmax) ? kz + kgc : kgc - 1;
+    const int ks = (kz < kmax) ? kz : 0;
+    int is = (i - igc) % itot; if (is < 0) is += itot;
+    int js = (j - jgc) % jtot; if (js < 0) js += jtot;
+    const size_t ij = (size_t)itot*jtot;
+    const TF pc = fft_norm<POW2>(packed[(size_t)is + (size_t)js*itot + (size_t)ks*ij], itot, jtot, ri, rj);
+    const size_t c = (size_t)ijc + (size_t)kd*icells*jcells;
+    p[c] = pc;
+    if (kz < kmax && i >= igc && i < igc + itot && j >= jgc && j < jgc + jtot)
+    {
+        const int iw = (is == 0) ? itot-1 : is-1, jsm = (js == 0) ? jtot-1 : js-1;
+        const TF pw = fft_norm<POW2>(packed[(size_t)iw + (size_t)js *itot + (size_t)ks*ij], itot, jtot, ri, rj);
+        const TF ps = fft_norm<POW2>(packed[(size_t)is + (size_t)jsm*itot + (size_t)ks*ij], itot, jtot, ri, rj);
+        const TF pb = (ks == 0) ? pc : fft_norm<POW2>(packed[(size_t)is + (size_t)js*itot + (size_t)(ks-1)*ij], itot, jtot, ri, rj);   // p[kstart-1] = p[kstart]
+        ut[c] -= (pc - pw) * dxi;
+        vt[c] -= (pc - ps) * dyi;
+        wt[c] -= (pc - pb) * dzhi[kd];
+    }
+}
+
+// forward transform, column solves, inverse transform: packed rhs -> packed (un-normalised) solution
+static int pres_spectral(mhh_pres_plan* P, const mhh_grid* g, void* p_packed, hipStream_t st)
+{
     MHH_FFT_TRY(rocfft_execution_info_set_stream(P->fwd_info, st));
     MHH_FFT_TRY(rocfft_execution_info_set_stream(P->bwd_info, st));
     void* in[1] = {p_packed}; void* out[1] = {P->spec};
@@ -542,12 +581,23 @@ MHH_API int mhh_pres_solve(mhh_pres_plan* P, const mhh_grid* g, const mhh_fields
     if (int e = pres_column_solve(P, g, st)) return e;
     void* in2[1] = {P->spec}; void* out2[1] = {p_packed};
     MHH_FFT_TRY(rocfft_execute(P->bwd, in2, out2, P->bwd_info));
+    return MHH_OK;
+}
+MHH_API int mhh_pres_solve(mhh_pres_plan* P, const mhh_grid* g, const mhh_fields* f, void* p_packed, void* stream)
+{
+    if (int e = check_grid(g)) return e;
+    MHH_REQUIRE(P && f && f->p, "null field");
+    MHH_REQUIRE(P->dtype == g->dtype && P->itot == g->itot && P->jtot == g->jtot && P->ktot == g->ktot, "plan/grid mismatch");
+    if (!p_packed) p_packed = P->packed;
+    hipStream_t st = as_stream(stream);
+    if (int e = pres_spectral(P, g, p_packed, st)) return e;
     const int nghost = (P->order == 2) ? 1 : 4;
-    dim3 ug((g->icells + 255)/256, g->jcells, g->kmax + nghost);
-    if (g->dtype == MHH_F64)
-        hipLaunchKernelGGL(unpack_kernel<double>, ug, dim3(256), 0, st, mp<double>(f->p), cp<double>(p_packed), P->order, g->itot, g->jtot, g->kmax, g->igc, g->jgc, g->kgc, g->icells, g->jcells);
-    else
-        hipLaunchKernelGGL(unpack_kernel<float>, ug, dim3(256), 0, st, mp<float>(f->p), cp<float>(p_packed), P->order, g->itot, g->jtot, g->kmax, g->igc, g->jgc, g->kgc, g->icells, g->jcells);
+    dim3 ug((g->icells*g->jcells + 255)/256, 1, g->kmax + nghost);
+    const bool pow2 = is_pow2(g->itot) && is_pow2(g->jtot);
+#define UNPACK(POW2, TF) hipLaunchKernelGGL((unpack_kernel<POW2, TF>), ug, dim3(256), 0, st, mp<TF>(f->p), cp<TF>(p_packed), P->order, g->itot, g->jtot, g->kmax, g->igc, g->jgc, g->kgc, g->icells, g->jcells)
+    if (g->dtype == MHH_F64) { if (pow2) UNPACK(true, double); else UNPACK(false, double); }
+    else                     { if (pow2) UNPACK(true, float);  else UNPACK(false, float); }
+#undef UNPACK
     MHH_LAUNCH_CHECK();
     return MHH_OK;
 }
@@ -702,6 +752,26 @@ MHH_API int mhh_pres_exec(mhh_pres_plan* P, const mhh_grid* g, const mhh_fields*
     if (!P->cb_ready || !(env && !strcmp(env, "1")))
     {
         if (int e = mhh_pres_input(P, g, f, dt, nullptr, stream)) return e;
+        const char* uo = getenv("MHH_PRES_UNPACK_OUT");                       // "0": unpack and output as two kernels (A/B)
+        if (P->order == 2 && !(uo && !strcmp(uo, "0")))
+        {
+            if (int e = check_grid(g)) return e;
+            MHH_REQUIRE(f && f->p && f->ut && f->vt && f->wt, "null field");
+            MHH_REQUIRE(P->dtype == g->dtype && P->itot == g->itot && P->jtot == g->jtot && P->ktot == g->ktot, "plan/grid mismatch");
+            hipStream_t st = as_stream(stream);
+            if (int e = pres_spectral(P, g, P->packed, st)) return e;
+            dim3 ug((g->icells*g->jcells + 255)/256, 1, g->kmax + 1);
+            const bool pow2 = is_pow2(g->itot) && is_pow2(g->jtot);
+#define CALL(TF) [&]{ const GridDev<TF> gd = make_grid<TF>(g); \
+                if (pow2) hipLaunchKernelGGL((unpack_out2_kernel<true, TF>), ug, dim3(256), 0, st, mp<TF>(f->p), cp<TF>(P->packed), mp<TF>(f->ut), mp<TF>(f->vt), mp<TF>(f->wt), gd.dzhi, \
+                                   gd.dxi_t, gd.dyi_t, g->itot, g->jtot, g->kmax, g->igc, g->jgc, g->kgc, g->icells, g->jcells); \
+                else hipLaunchKernelGGL((unpack_out2_kernel<false, TF>), ug, dim3(256), 0, st, mp<TF>(f->p), cp<TF>(P->packed), mp<TF>(f->ut), mp<TF>(f->vt), mp<TF>(f->wt), gd.dzhi, \
+                                   gd.dxi_t, gd.dyi_t, g->itot, g->jtot, g->kmax, g->igc, g->jgc, g->kgc, g->icells, g->jcells); return MHH_OK; }()
+            if (int e = MHH_DISPATCH(g, CALL)) return e;
+#undef CALL
+            MHH_LAUNCH_CHECK();
+            return MHH_OK;
+        }
         if (int e = mhh_pres_solve(P, g, f, nullptr, stream)) return e;
         return mhh_pres_output(P, g, f, stream);
     }

@@ -75,6 +75,13 @@ class HotPath:
         self._comm_stream = None
         self.device = torch.device(device)
         self.on_gpu = self.device.type == "cuda"
+        # Rehearsal of the N > 1 path on a box with fewer GPUs than ranks: several ranks share one card and talk over
+        # gloo, which has no device-side send/recv or all-to-all, so the MESSAGES (never the compute) pass through host
+        # copies. With the nccl backend (= RCCL, the product path) the device buffers go to the collective as they are.
+        self._host_staged = False
+        if self.on_gpu and npy > 1:
+            import torch.distributed as dist
+            self._host_staged = dist.get_backend(group) == "gloo"
         if self.slab and cfg["pres"] != 2:
             raise ValueError("slab decomposition implements pres_2 (BASELINE.json multi-GPU configs use pres_2)")
         z = moser_z(ktot, cfg["size"][2]) if case == "moser600" else None
@@ -217,13 +224,18 @@ class HotPath:
         else:
             south, north = (self.rank - 1) % self.npy, (self.rank + 1) % self.npy
             ranks = dist.get_process_group_ranks(self.group) if self.group is not None else list(range(self.npy))
+            m = [s_north, s_south, r_south, r_north]
+            if self._host_staged:
+                m = [s_north.cpu(), s_south.cpu(), self.torch.empty_like(r_south, device="cpu"), self.torch.empty_like(r_north, device="cpu")]
             ops = []
-            if rn: ops.append(dist.P2POp(dist.isend, s_north, ranks[north], self.group))
-            if rs: ops.append(dist.P2POp(dist.isend, s_south, ranks[south], self.group))
-            if rn: ops.append(dist.P2POp(dist.irecv, r_south, ranks[south], self.group))
-            if rs: ops.append(dist.P2POp(dist.irecv, r_north, ranks[north], self.group))
+            if rn: ops.append(dist.P2POp(dist.isend, m[0], ranks[north], self.group))
+            if rs: ops.append(dist.P2POp(dist.isend, m[1], ranks[south], self.group))
+            if rn: ops.append(dist.P2POp(dist.irecv, m[2], ranks[south], self.group))
+            if rs: ops.append(dist.P2POp(dist.irecv, m[3], ranks[north], self.group))
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
+            if self._host_staged:
+                r_south.copy_(m[2]); r_north.copy_(m[3])
         self._ok(self.lib.mhh_halo_unpack_rows(self.G, arr, nf, rs, rn, r_south.data_ptr(), r_north.data_ptr(), self.stream))
 
     def _halo2d(self, t):
@@ -235,6 +247,8 @@ class HotPath:
         import torch.distributed as dist
         t[:, :g.igc] = t[:, g.iend-g.igc:g.iend].clone(); t[:, g.iend:] = t[:, g.istart:g.istart+g.igc].clone()
         s_north, s_south = t[g.jend-g.jgc:g.jend].contiguous(), t[g.jstart:g.jstart+g.jgc].contiguous()
+        if self._host_staged:
+            s_north, s_south = s_north.cpu(), s_south.cpu()
         r_south, r_north = self.torch.empty_like(s_north), self.torch.empty_like(s_south)
         south, north = (self.rank - 1) % self.npy, (self.rank + 1) % self.npy
         ranks = dist.get_process_group_ranks(self.group) if self.group is not None else list(range(self.npy))
@@ -242,7 +256,7 @@ class HotPath:
                dist.P2POp(dist.irecv, r_south, ranks[south], self.group), dist.P2POp(dist.irecv, r_north, ranks[north], self.group)]
         for w in dist.batch_isend_irecv(ops):
             w.wait()
-        t[:g.jgc] = r_south; t[g.jend:] = r_north
+        t[:g.jgc] = r_south.to(t.device); t[g.jend:] = r_north.to(t.device)
 
     def cyclic_prognostic(self):
         self.halo(self._prog)
@@ -330,6 +344,11 @@ class HotPath:
             self.xrecv.copy_(self.xsend)
             return
         import torch.distributed as dist
+        if self._host_staged:
+            hs = self.xsend.cpu(); hr = self.torch.empty_like(hs)
+            dist.all_to_all_single(hr, hs, group=self.group)
+            self.xrecv.copy_(hr)
+            return
         dist.all_to_all_single(self.xrecv, self.xsend, group=self.group)
 
     def step(self):
@@ -347,7 +366,7 @@ class HotPath:
         if self.npy == 1:
             return v
         import torch.distributed as dist
-        t = self.torch.tensor([v], device=self.device, dtype=self.torch.float64)
+        t = self.torch.tensor([v], device=("cpu" if self._host_staged else self.device), dtype=self.torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return float(t.item())
 

@@ -365,6 +365,58 @@ def test_pres_exec_callback_fused_equals_staged(be, order, dtype):
         assert not np.array_equal(out["fused"][0], c.p)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_unpack_normalisation_is_two_divisions_bit_for_bit(be, dtype):
+    """The normalisation after the inverse transform is value / jtot / itot (src/fft.cxx); with power-of-two extents the
+    library multiplies by the exact reciprocals instead -- the bits must be those of the divisions, on values across
+    the whole exponent range. An identity 'solve' is not available, so this drives the spectral path with a packed
+    field whose transform pair returns itot*jtot*x up to rounding and checks the unpacked p against the division of the
+    very same packed solution, read back through mhh_pres_solve's in-place buffer."""
+    for shape in ((16, 8, 6), (16, 12, 6), (8, 1, 6)):
+        g = cm.grid_2nd(*shape, gc=(2, 2, 1), dtype=dtype)
+        c = cm.Case(g, rho="random", periodic=True); Gh = g.host_struct()
+        d = B.DevCase(be, c); f = d.fields()
+        plan = capi.PLAN()
+        B.ok(be, be.lib.mhh_pres_plan_create(Gh, 2, ptr(g.dz), ptr(g.dzhi), ptr(g.dzi4), ptr(g.dzhi4), ptr(c.rhoref), ptr(c.rhorefh), C.byref(plan)))
+        rng = np.random.default_rng(5)
+        pk0 = (rng.standard_normal((g.ktot, g.jtot, g.itot)) * 10.0**rng.integers(-30, 30, (g.ktot, g.jtot, g.itot))).astype(dtype)
+        pk = be.arr(pk0)
+        B.ok(be, be.lib.mhh_pres_solve(plan, d.G, C.byref(f), be.ptr(pk), be.stream))
+        sol = be.host(pk)                                   # the un-normalised solution the unpack read
+        want = (sol / dtype(g.jtot) / dtype(g.itot)).astype(dtype)
+        got = be.host(d.p)[g.kstart:g.kend, g.jstart:g.jend, g.istart:g.iend]
+        assert same(got, want), (shape, cm.ulp_diff(got, want))
+        be.lib.mhh_pres_plan_destroy(plan)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pres2_exec_unpack_and_output_in_one_kernel_equals_two(be, dtype):
+    """mhh_pres_exec (order 2) unpacks the solution and applies Pres_2::output in one kernel; MHH_PRES_UNPACK_OUT=0 runs
+    them as the two kernels of mhh_pres_solve + mhh_pres_output. Same bits: p with every ghost cell, ut, vt, wt."""
+    gl = [cm.grid_2nd(16, 12, 10, gc=(1, 1, 1), dtype=dtype), cm.grid_2nd(12, 10, 8, gc=(3, 3, 2), dtype=dtype), cm.grid_2nd(12, 1, 8, gc=(1, 1, 1), dtype=dtype),
+          cm.grid_2nd(4, 3, 6, gc=(3, 3, 1), dtype=dtype), cm.grid_2nd(300, 5, 4, gc=(2, 2, 1), dtype=dtype), cm.grid_2nd(16, 8, 6, gc=(2, 2, 1), dtype=dtype),
+          cm.grid_2nd(8, 1, 6, gc=(1, 1, 1), dtype=dtype)]
+    for g in gl:
+        c = cm.Case(g, rho="random", periodic=True)
+        Gh = g.host_struct(); dt = 0.7
+        out = {}
+        for form in ("one", "two"):
+            d = B.DevCase(be, c); f = d.fields()
+            plan = capi.PLAN()
+            B.ok(be, be.lib.mhh_pres_plan_create(Gh, 2, ptr(g.dz), ptr(g.dzhi), ptr(g.dzi4), ptr(g.dzhi4), ptr(c.rhoref), ptr(c.rhorefh), C.byref(plan)))
+            if form == "two":
+                os.environ["MHH_PRES_UNPACK_OUT"] = "0"
+            try:
+                B.ok(be, be.lib.mhh_pres_exec(plan, d.G, C.byref(f), dt, be.stream))
+            finally:
+                os.environ.pop("MHH_PRES_UNPACK_OUT", None)
+            out[form] = [be.host(x) for x in (d.p, d.ut, d.vt, d.wt)]
+            be.lib.mhh_pres_plan_destroy(plan)
+        for x, y, nm in zip(out["one"], out["two"], ("p", "ut", "vt", "wt")):
+            assert same(x, y), (g.shape3, nm, cm.ulp_diff(x, y))
+        assert not np.array_equal(out["one"][1], c.ut)
+
+
 @pytest.mark.parametrize("adv,dif", [(cm.ADVEC_2I4, cm.DIFF_2), (cm.ADVEC_2I62, cm.DIFF_SMAG2), (cm.ADVEC_2I53, cm.DIFF_SMAG2), (cm.ADVEC_4M, cm.DIFF_4)])
 def test_rhs_exec_other_scheme_pairs_run_as_two_calls(be, adv, dif):
     """mhh_rhs_exec accepts every pair of valid schemes: pairs without a fused kernel run Advec::exec then Diff::exec."""
@@ -502,8 +554,9 @@ def test_exec_viscosity_marching_form_equals_cell_form(be, sm, neutral, dtype):
 @pytest.mark.parametrize("order", [2, 4])
 def test_pres(be, order, dtype):
     O = cm.oracle()
-    gl = [cm.grid_2nd(16, 12, 10, gc=(1, 1, 1), dtype=dtype), cm.grid_2nd(12, 10, 8, gc=(3, 3, 1), dtype=dtype), cm.grid_2nd(12, 1, 8, gc=(1, 1, 1), dtype=dtype)] if order == 2 \
-        else [cm.grid_4th(16, 12, 12, dtype=dtype), cm.grid_4th(12, 1, 8, dtype=dtype)]
+    gl = [cm.grid_2nd(16, 12, 10, gc=(1, 1, 1), dtype=dtype), cm.grid_2nd(12, 10, 8, gc=(3, 3, 1), dtype=dtype), cm.grid_2nd(12, 1, 8, gc=(1, 1, 1), dtype=dtype),
+          cm.grid_2nd(16, 8, 6, gc=(2, 2, 1), dtype=dtype)] if order == 2 \
+        else [cm.grid_4th(16, 12, 12, dtype=dtype), cm.grid_4th(12, 1, 8, dtype=dtype), cm.grid_4th(16, 8, 8, dtype=dtype)]
     tol = 1e-11 if dtype == np.float64 else 2e-4
     for g in gl:
         c = cm.Case(g, rho=("random" if order == 2 else "one"), periodic=True)
