@@ -96,6 +96,9 @@ def main():
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
                     help="cpu = REHEARSAL of this script's control flow (ranks, exchanges, JSON line) with gloo and the test-only CPU "
                          "emulation of the kernels named by MHH_LIB; never a measurement")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="REHEARSAL of N > 1 on a one-GPU box: every rank runs its HIP kernels on cuda:0, messages go over gloo "
+                         "through host copies; never a measurement")
     ap.add_argument("--force-slab", action="store_true", help="N=1 only: run the slab code path (halo pack/unpack, split pressure solve) with local copies as exchanges")
     args = ap.parse_args()
 
@@ -107,9 +110,12 @@ def main():
             sys.exit("bench.py --gpus %d must be launched through torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
     on_gpu = args.device == "cuda"
     if on_gpu:
+        if args.share_gpu:
+            local = 0
         torch.cuda.set_device(local)
         if world > 1:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            if args.share_gpu: dist.init_process_group("gloo")
+            else:              dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
         if not os.environ.get("MHH_LIB"):
             sys.exit("--device cpu is a rehearsal mode: point MHH_LIB at tests/emul/libmhh_emul.so")
@@ -176,7 +182,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], device=("cuda" if on_gpu else "cpu"), dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=("cuda" if on_gpu and not args.share_gpu else "cpu"), dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms = 1e3 * elapsed / args.steps
@@ -212,6 +218,8 @@ def main():
         out["roofline"]["traffic_source"] = "profiles/r1e_kernels_pmc.md"
     if not on_gpu:
         out["data"] = "synthetic; CPU REHEARSAL of the script (emulated kernels, gloo): not a measurement"
+    if on_gpu and args.share_gpu:
+        out["data"] = "synthetic; REHEARSAL of the N > 1 path with all ranks on one GPU (gloo, host-staged messages): not a measurement"
     if rank == 0 and world == 1 and not args.no_cpu_baseline and on_gpu:
         out["cpu_baseline"] = cpu_baseline("drycblles" if case == "gabls1" else case)
     hp.close()
