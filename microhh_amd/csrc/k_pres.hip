@@ -26,6 +26,7 @@ struct mhh_pres_plan
 {
     int order = 0, dtype = 0;
     int itot = 0, jtot = 0, ktot = 0, nxh = 0;
+    int nxp = 0;                 // row pitch of the spectral array in complex elements (>= nxh)
     size_t esz = 8;
     // coefficient tables (device), element type = dtype
     void* bmati = nullptr; void* bmatj = nullptr;
@@ -33,7 +34,7 @@ struct mhh_pres_plan
     void* m[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};     // pres_4
     // buffers
     void* packed = nullptr;      // imax*jmax*kmax reals
-    void* spec = nullptr;        // nxh*jtot*ktot complex
+    void* spec = nullptr;        // nxp*jtot*ktot complex (rows of nxh modes at pitch nxp)
     void* work = nullptr;        // scratch of the k-sweep: work3d (pres_2) / 7 band arrays + rhs (pres_4)
     rocfft_plan fwd = nullptr, bwd = nullptr;
     rocfft_execution_info fwd_info = nullptr, bwd_info = nullptr;
@@ -149,8 +150,8 @@ static int make_fft(mhh_pres_plan* P, bool forward, rocfft_plan* plan, rocfft_ex
 {
     const size_t lengths[2] = {(size_t)P->itot, (size_t)P->jtot};
     const size_t rstr[2] = {1, (size_t)P->itot};
-    const size_t cstr[2] = {1, (size_t)P->nxh};
-    const size_t rdist = (size_t)P->itot*P->jtot, cdist = (size_t)P->nxh*P->jtot;
+    const size_t cstr[2] = {1, (size_t)P->nxp};
+    const size_t rdist = (size_t)P->itot*P->jtot, cdist = (size_t)P->nxp*P->jtot;
     const size_t off[2] = {0, 0};
     rocfft_plan_description d = nullptr;
     MHH_FFT_TRY(rocfft_plan_description_create(&d));
@@ -190,6 +191,7 @@ MHH_API void mhh_pres_plan_destroy(mhh_pres_plan* P)
 }
 
 static int hdma_factor(mhh_pres_plan* P);
+static int tdma_factor(mhh_pres_plan* P);
 static int pres_cb_setup(mhh_pres_plan* P);
 MHH_API int mhh_pres_plan_create(const mhh_grid* g, int order, const void* host_dz, const void* host_dzhi, const void* host_dzi4, const void* host_dzhi4,
                                  const void* host_rhoref, const void* host_rhorefh, mhh_pres_plan** out)
@@ -202,10 +204,17 @@ MHH_API int mhh_pres_plan_create(const mhh_grid* g, int order, const void* host_
     else            MHH_REQUIRE(host_dzi4 && host_dzhi4 && g->kgc >= 2 && g->igc >= 2 && g->jgc >= 2 && g->kmax >= 4, "pres_4 inputs");
     mhh_pres_plan* P = new mhh_pres_plan();
     P->order = order; P->dtype = g->dtype; P->itot = g->itot; P->jtot = g->jtot; P->ktot = g->ktot; P->nxh = g->itot/2 + 1;
+    {   // row pitch of the spectral array: itot/2+1 complex numbers is never a whole number of 128-byte lines, and the column
+        // tiles of rocFFT's y pass then straddle lines (512^3 fp64: 0.72 -> 0.48 ms per pass with rows padded to 264).
+        // MHH_PRES_PITCH=n pads to a multiple of n elements instead (1: no padding) for A/B runs.
+        const char* pe = getenv("MHH_PRES_PITCH");
+        const int al = pe ? atoi(pe) : 128 / (2*((g->dtype == MHH_F64) ? 8 : 4));
+        P->nxp = (al > 1) ? (P->nxh + al-1)/al*al : P->nxh;
+    }
     P->esz = (g->dtype == MHH_F64) ? 8 : 4;
     int e = (g->dtype == MHH_F64) ? plan_tables<double>(P, g, host_dz, host_dzhi, host_dzi4, host_dzhi4, host_rhoref, host_rhorefh)
                                   : plan_tables<float>(P, g, host_dz, host_dzhi, host_dzi4, host_dzhi4, host_rhoref, host_rhorefh);
-    const size_t nreal = (size_t)g->itot*g->jtot*g->ktot, ncol = (size_t)P->nxh*g->jtot;
+    const size_t nreal = (size_t)g->itot*g->jtot*g->ktot, ncol = (size_t)P->nxp*g->jtot;
     const size_t nwork = (order == 2) ? ncol*g->ktot : ncol*(g->ktot+4)*7;   // pres_4: the 7 factored bands
     if (!e) { hipError_t h = hipMalloc(&P->packed, nreal*P->esz); if (h != hipSuccess) { set_error("hipMalloc packed: %s", hipGetErrorString(h)); e = MHH_ENOMEM; } }
     if (!e) { hipError_t h = hipMalloc(&P->spec, ncol*g->ktot*2*P->esz); if (h != hipSuccess) { set_error("hipMalloc spec: %s", hipGetErrorString(h)); e = MHH_ENOMEM; } }
@@ -219,6 +228,7 @@ MHH_API int mhh_pres_plan_create(const mhh_grid* g, int order, const void* host_
         if (!e) e = pres_cb_setup(P);
     }
     if (!e && order == 4) e = hdma_factor(P);
+    if (!e && order == 2) e = tdma_factor(P);
     if (e) { mhh_pres_plan_destroy(P); return e; }
     *out = P;
     return MHH_OK;
@@ -295,52 +305,117 @@ MHH_API int mhh_pres_input(mhh_pres_plan* P, const mhh_grid* g, const mhh_fields
 // =======================================================================================================
 // spectral solve, pres_2: Thomas algorithm per (kx,ky) column (src/pres_2.cxx:289-330 matrix, :202-263 tdma)
 // =======================================================================================================
+// The pivots w2 and the eliminated upper diagonal w3 depend on the grid and (kx, ky) only (the reference regenerates them
+// in every solve, src/pres_2.cxx:213-249): w3 is factored ONCE at plan creation by the same recurrence (tdma_factor_kernel)
+// and kept (one real per spectral element); the forward sweep of a solve runs the cheap recurrence in registers and
+// touches no scratch at all, the backward sweep reads w3 -- one array write per solve less than the reference's form.
+// Both sweeps work in batches of U levels: the U right-hand sides (and w3 values) of a batch are loaded before its
+// dependent chain starts, so every lane keeps U loads in flight instead of one.
 template<class TF>
-__global__ void __launch_bounds__(64) tdma_kernel(C2<TF>* __restrict__ p, TF* __restrict__ work3d,
-                                                  const TF* __restrict__ bmati, const TF* __restrict__ bmatj,
-                                                  const TF* __restrict__ a, const TF* __restrict__ c, const TF* __restrict__ dz, const TF* __restrict__ rho,
-                                                  int nxh, int jtot, int kmax)
+__device__ __forceinline__ TF tdma_diag(const TF* __restrict__ a, const TF* __restrict__ c, const TF* __restrict__ dz, const TF* __restrict__ rho,
+                                        TF bm, bool mean, int k, int kmax)
 {
-    const int kx = blockIdx.x*64 + threadIdx.x, ky = blockIdx.y;
+    const TF dz2 = dz[k]*dz[k];
+    TF b = dz2 * rho[k]*bm - (a[k]+c[k]);
+    if (k == 0) b += a[0];
+    if (k == kmax-1) { if (mean) b -= c[k]; else b += c[k]; }
+    return b;
+}
+template<class TF>
+__global__ void __launch_bounds__(64) tdma_factor_kernel(TF* __restrict__ work3d, const TF* __restrict__ bmati, const TF* __restrict__ bmatj,
+                                                         const TF* __restrict__ a, const TF* __restrict__ c, const TF* __restrict__ dz, const TF* __restrict__ rho,
+                                                         int nxh, int nxp, int jtot, int kmax)
+{
+    const size_t ncol = (size_t)nxp*jtot, col = (size_t)blockIdx.x*64 + threadIdx.x;
+    if (col >= ncol) return;
+    const int ky = (int)(col / nxp), kx = (int)(col - (size_t)ky*nxp);
     if (kx >= nxh) return;
-    const size_t ncol = (size_t)nxh*jtot, col = kx + (size_t)ky*nxh;
     const TF bm = bmati[kx] + bmatj[ky];
     const bool mean = (kx == 0 && ky == 0);
-    TF w2; C2<TF> pp;
-    {   // k = 0
-        const TF dz2 = dz[0]*dz[0];
-        TF b = dz2 * rho[0]*bm - (a[0]+c[0]);
-        b += a[0];
-        if (kmax == 1) { if (mean) b -= c[0]; else b += c[0]; }
-        C2<TF> q = p[col];
-        q.x = dz2 * q.x; q.y = dz2 * q.y;
-        w2 = b;
-        q.x /= w2; q.y /= w2;
-        p[col] = q; pp = q;
-    }
+    TF w2 = tdma_diag(a, c, dz, rho, bm, mean, 0, kmax);
+    work3d[col] = TF(0);
     for (int k=1; k<kmax; ++k)
     {
-        const size_t e = col + (size_t)k*ncol;
-        const TF dz2 = dz[k]*dz[k];
-        TF b = dz2 * rho[k]*bm - (a[k]+c[k]);
-        if (k == kmax-1) { if (mean) b -= c[k]; else b += c[k]; }
-        C2<TF> q = p[e];
-        q.x = dz2 * q.x; q.y = dz2 * q.y;
         const TF w3 = c[k-1] / w2;
-        work3d[e] = w3;
-        w2 = b - a[k]*w3;
-        q.x -= a[k]*pp.x; q.y -= a[k]*pp.y;
-        q.x /= w2; q.y /= w2;
-        p[e] = q; pp = q;
+        work3d[col + (size_t)k*ncol] = w3;
+        w2 = tdma_diag(a, c, dz, rho, bm, mean, k, kmax) - a[k]*w3;
     }
-    for (int k=kmax-2; k>=0; --k)
+}
+template<class TF>
+__global__ void __launch_bounds__(64) tdma_kernel(C2<TF>* __restrict__ p, const TF* __restrict__ work3d,
+                                                  const TF* __restrict__ bmati, const TF* __restrict__ bmatj,
+                                                  const TF* __restrict__ a, const TF* __restrict__ c, const TF* __restrict__ dz, const TF* __restrict__ rho,
+                                                  int nxh, int nxp, int jtot, int kmax)
+{
+    constexpr int U = 8;
+    // one thread per (kx, ky) column, threads running over the flattened spectral plane (row pitch nxp)
+    const size_t ncol = (size_t)nxp*jtot, col = (size_t)blockIdx.x*64 + threadIdx.x;
+    if (col >= ncol) return;
+    const int ky = (int)(col / nxp), kx = (int)(col - (size_t)ky*nxp);
+    if (kx >= nxh) return;
+    const TF bm = bmati[kx] + bmatj[ky];
+    const bool mean = (kx == 0 && ky == 0);
+    TF w2 = TF(1); C2<TF> pp{TF(0), TF(0)};
+    for (int k0=0; k0<kmax; k0+=U)
     {
-        const size_t e = col + (size_t)k*ncol;
-        const TF w3 = work3d[e+ncol];
-        C2<TF> q = p[e];
-        q.x -= w3*pp.x; q.y -= w3*pp.y;
-        p[e] = q; pp = q;
+        C2<TF> q[U];
+#pragma unroll
+        for (int n=0; n<U; ++n) if (k0+n < kmax) q[n] = p[col + (size_t)(k0+n)*ncol];
+#pragma unroll
+        for (int n=0; n<U; ++n)
+        {
+            const int k = k0+n;
+            if (k < kmax)
+            {
+                const TF dz2 = dz[k]*dz[k];
+                const TF b = tdma_diag(a, c, dz, rho, bm, mean, k, kmax);
+                C2<TF> r = q[n];
+                r.x = dz2 * r.x; r.y = dz2 * r.y;
+                if (k == 0) w2 = b;
+                else
+                {
+                    const TF w3 = c[k-1] / w2;
+                    w2 = b - a[k]*w3;
+                    r.x -= a[k]*pp.x; r.y -= a[k]*pp.y;
+                }
+                r.x /= w2; r.y /= w2;
+                q[n] = r; pp = r;
+            }
+        }
+#pragma unroll
+        for (int n=0; n<U; ++n) if (k0+n < kmax) p[col + (size_t)(k0+n)*ncol] = q[n];
     }
+    // back substitution, top batch first: levels kmax-2 .. 0
+    for (int k1=kmax-2; k1>=0; k1-=U)
+    {
+        C2<TF> q[U]; TF w3[U];
+#pragma unroll
+        for (int n=0; n<U; ++n) if (k1-n >= 0) { q[n] = p[col + (size_t)(k1-n)*ncol]; w3[n] = work3d[col + (size_t)(k1-n+1)*ncol]; }
+#pragma unroll
+        for (int n=0; n<U; ++n)
+            if (k1-n >= 0)
+            {
+                C2<TF> r = q[n];
+                r.x -= w3[n]*pp.x; r.y -= w3[n]*pp.y;
+                q[n] = r; pp = r;
+            }
+#pragma unroll
+        for (int n=0; n<U; ++n) if (k1-n >= 0) p[col + (size_t)(k1-n)*ncol] = q[n];
+    }
+}
+
+static int tdma_factor(mhh_pres_plan* P)
+{
+    dim3 grid((unsigned)(((size_t)P->nxp*P->jtot + 63)/64));
+    if (P->dtype == MHH_F64)
+        hipLaunchKernelGGL(tdma_factor_kernel<double>, grid, dim3(64), 0, 0, (double*)P->work, cp<double>(P->bmati), cp<double>(P->bmatj),
+                           cp<double>(P->a), cp<double>(P->c), cp<double>(P->dz), cp<double>(P->rhoref), P->nxh, P->nxp, P->jtot, P->ktot);
+    else
+        hipLaunchKernelGGL(tdma_factor_kernel<float>, grid, dim3(64), 0, 0, (float*)P->work, cp<float>(P->bmati), cp<float>(P->bmatj),
+                           cp<float>(P->a), cp<float>(P->c), cp<float>(P->dz), cp<float>(P->rhoref), P->nxh, P->nxp, P->jtot, P->ktot);
+    hipError_t h = hipGetLastError(); if (h == hipSuccess) h = hipStreamSynchronize(0);
+    if (h != hipSuccess) { set_error("tdma_factor: %s", hipGetErrorString(h)); return MHH_EHIP; }
+    return MHH_OK;
 }
 
 // =======================================================================================================
@@ -354,11 +429,11 @@ __global__ void __launch_bounds__(64) hdma_factor_kernel(TF* __restrict__ W,
                                                   const TF* __restrict__ bmati, const TF* __restrict__ bmatj,
                                                   const TF* __restrict__ M1, const TF* __restrict__ M2, const TF* __restrict__ M3, const TF* __restrict__ M4,
                                                   const TF* __restrict__ M5, const TF* __restrict__ M6, const TF* __restrict__ M7,
-                                                  int nxh, int jtot, int kmax)
+                                                  int nxh, int nxp, int jtot, int kmax)
 {
     const int kx = blockIdx.x*64 + threadIdx.x, ky = blockIdx.y;
     if (kx >= nxh) return;
-    const size_t ncol = (size_t)nxh*jtot, col = kx + (size_t)ky*nxh;
+    const size_t ncol = (size_t)nxp*jtot, col = kx + (size_t)ky*nxp;
     const int n = kmax+4;
     const bool mean = (kx == 0 && ky == 0);
     TF* __restrict__ m1 = W + 0*(size_t)n*ncol + col; TF* __restrict__ m2 = W + 1*(size_t)n*ncol + col;
@@ -414,11 +489,11 @@ static int hdma_factor(mhh_pres_plan* P)
     if (P->dtype == MHH_F64)
         hipLaunchKernelGGL(hdma_factor_kernel<double>, grid, dim3(64), 0, 0, (double*)P->work, cp<double>(P->bmati), cp<double>(P->bmatj),
                            cp<double>(P->m[0]), cp<double>(P->m[1]), cp<double>(P->m[2]), cp<double>(P->m[3]), cp<double>(P->m[4]), cp<double>(P->m[5]), cp<double>(P->m[6]),
-                           P->nxh, P->jtot, P->ktot);
+                           P->nxh, P->nxp, P->jtot, P->ktot);
     else
         hipLaunchKernelGGL(hdma_factor_kernel<float>, grid, dim3(64), 0, 0, (float*)P->work, cp<float>(P->bmati), cp<float>(P->bmatj),
                            cp<float>(P->m[0]), cp<float>(P->m[1]), cp<float>(P->m[2]), cp<float>(P->m[3]), cp<float>(P->m[4]), cp<float>(P->m[5]), cp<float>(P->m[6]),
-                           P->nxh, P->jtot, P->ktot);
+                           P->nxh, P->nxp, P->jtot, P->ktot);
     hipError_t h = hipGetLastError(); if (h == hipSuccess) h = hipStreamSynchronize(0);
     if (h != hipSuccess) { set_error("hdma_factor: %s", hipGetErrorString(h)); return MHH_EHIP; }
     return MHH_OK;
@@ -428,11 +503,12 @@ static int hdma_factor(mhh_pres_plan* P)
 // reference's kmax+4 system is spectral level r-2; the two boundary rows on either side have a zero right-hand side
 // and live in registers only, so the sweeps run in place on p without a scratch copy of the rhs.
 template<class TF>
-__global__ void __launch_bounds__(128) hdma_solve_kernel(TF* __restrict__ p, const TF* __restrict__ W, size_t ncol, int kmax)
+__global__ void __launch_bounds__(128) hdma_solve_kernel(TF* __restrict__ p, const TF* __restrict__ W, size_t ncol, int nxh, int nxp, int kmax)
 {
     const size_t t = (size_t)blockIdx.x*128 + threadIdx.x;
     if (t >= 2*ncol) return;
     const size_t col = t >> 1;
+    if ((int)(col % nxp) >= nxh) return;                         // padding of the row pitch
     const int n = kmax+4;
     const TF* __restrict__ m1 = W + 0*(size_t)n*ncol + col; const TF* __restrict__ m2 = W + 1*(size_t)n*ncol + col;
     const TF* __restrict__ m3 = W + 2*(size_t)n*ncol + col; const TF* __restrict__ m4 = W + 3*(size_t)n*ncol + col;
@@ -519,19 +595,20 @@ static int pres_column_solve(mhh_pres_plan* P, const mhh_grid* g, hipStream_t st
     dim3 grid((P->nxh + 63)/64, P->jtot);
     if (P->order == 2)
     {
+        grid = dim3((unsigned)(((size_t)P->nxp*P->jtot + 63)/64));
         if (g->dtype == MHH_F64)
-            hipLaunchKernelGGL(tdma_kernel<double>, grid, dim3(64), 0, st, (C2<double>*)P->spec, (double*)P->work, cp<double>(P->bmati), cp<double>(P->bmatj),
-                               cp<double>(P->a), cp<double>(P->c), cp<double>(P->dz), cp<double>(P->rhoref), P->nxh, P->jtot, P->ktot);
+            hipLaunchKernelGGL(tdma_kernel<double>, grid, dim3(64), 0, st, (C2<double>*)P->spec, cp<double>(P->work), cp<double>(P->bmati), cp<double>(P->bmatj),
+                               cp<double>(P->a), cp<double>(P->c), cp<double>(P->dz), cp<double>(P->rhoref), P->nxh, P->nxp, P->jtot, P->ktot);
         else
-            hipLaunchKernelGGL(tdma_kernel<float>, grid, dim3(64), 0, st, (C2<float>*)P->spec, (float*)P->work, cp<float>(P->bmati), cp<float>(P->bmatj),
-                               cp<float>(P->a), cp<float>(P->c), cp<float>(P->dz), cp<float>(P->rhoref), P->nxh, P->jtot, P->ktot);
+            hipLaunchKernelGGL(tdma_kernel<float>, grid, dim3(64), 0, st, (C2<float>*)P->spec, cp<float>(P->work), cp<float>(P->bmati), cp<float>(P->bmatj),
+                               cp<float>(P->a), cp<float>(P->c), cp<float>(P->dz), cp<float>(P->rhoref), P->nxh, P->nxp, P->jtot, P->ktot);
     }
     else
     {
-        const size_t ncol = (size_t)P->nxh*P->jtot;
+        const size_t ncol = (size_t)P->nxp*P->jtot;
         dim3 sg((unsigned)((2*ncol + 127)/128));
-        if (g->dtype == MHH_F64) hipLaunchKernelGGL(hdma_solve_kernel<double>, sg, dim3(128), 0, st, (double*)P->spec, cp<double>(P->work), ncol, P->ktot);
-        else                     hipLaunchKernelGGL(hdma_solve_kernel<float>,  sg, dim3(128), 0, st, (float*)P->spec,  cp<float>(P->work),  ncol, P->ktot);
+        if (g->dtype == MHH_F64) hipLaunchKernelGGL(hdma_solve_kernel<double>, sg, dim3(128), 0, st, (double*)P->spec, cp<double>(P->work), ncol, P->nxh, P->nxp, P->ktot);
+        else                     hipLaunchKernelGGL(hdma_solve_kernel<float>,  sg, dim3(128), 0, st, (float*)P->spec,  cp<float>(P->work),  ncol, P->nxh, P->nxp, P->ktot);
     }
     MHH_LAUNCH_CHECK();
     return MHH_OK;

@@ -207,7 +207,6 @@ class HotPath:
 
     def _exchange_ns(self, tensors, rows_south=None, rows_north=None):
         """North-south part of halo(): pack, ring exchange (or local swap on one rank), unpack -- on the current stream."""
-        import torch.distributed as dist
         arr = self._ptrs(tensors)
         g, nf = self.grid, len(tensors)
         rs = g.jgc if rows_south is None else rows_south
@@ -215,28 +214,41 @@ class HotPath:
         key = (nf, rs, rn)
         if key not in self._halo:
             per_row = nf * g.kcells * g.icells
-            mk = lambda rows: self.torch.zeros(max(1, rows * per_row), device=self.device, dtype=self.td)
-            self._halo[key] = [mk(rs), mk(rn), mk(rn), mk(rs)]      # send south, send north, recv from south, recv from north
-        s_south, s_north, r_south, r_north = self._halo[key]
-        self._ok(self.lib.mhh_halo_pack_rows(self.G, arr, nf, rs, rn, s_south.data_ptr(), s_north.data_ptr(), self.stream))
+            # one send and one receive buffer, [northbound | southbound]: what I send north arrives as my north neighbour's
+            # "from south" part, so with two ranks (north == south) the whole buffer is ONE message pair
+            nn, ns = rn * per_row, rs * per_row
+            send = self.torch.zeros(max(1, nn + ns), device=self.device, dtype=self.td)
+            recv = self.torch.zeros(max(1, nn + ns), device=self.device, dtype=self.td)
+            self._halo[key] = [send[nn:nn+ns], send[:nn], recv[:nn], recv[nn:nn+ns], send, recv]   # send south, send north, recv from south, recv from north
+        s_south, s_north, r_south, r_north, send, recv = self._halo[key]
+        isz = send.element_size()                                   # (an empty view has a null data_ptr: offsets by hand)
+        off_s = s_north.numel() * isz
+        self._ok(self.lib.mhh_halo_pack_rows(self.G, arr, nf, rs, rn, send.data_ptr() + off_s, send.data_ptr(), self.stream))
+        self._ring(rs, rn, s_south, s_north, r_south, r_north, send, recv)
+        self._ok(self.lib.mhh_halo_unpack_rows(self.G, arr, nf, rs, rn, recv.data_ptr(), recv.data_ptr() + off_s, self.stream))
+
+    def _ring(self, rs, rn, s_south, s_north, r_south, r_north, send, recv):
+        """The message part of _exchange_ns: my northbound rows to the north neighbour, southbound rows to the south one."""
+        import torch.distributed as dist
         if self.npy == 1:          # both neighbours are this rank: the exchange is a local swap
             r_south.copy_(s_north); r_north.copy_(s_south)
         else:
             south, north = (self.rank - 1) % self.npy, (self.rank + 1) % self.npy
             ranks = dist.get_process_group_ranks(self.group) if self.group is not None else list(range(self.npy))
-            m = [s_north, s_south, r_south, r_north]
-            if self._host_staged:
-                m = [s_north.cpu(), s_south.cpu(), self.torch.empty_like(r_south, device="cpu"), self.torch.empty_like(r_north, device="cpu")]
-            ops = []
-            if rn: ops.append(dist.P2POp(dist.isend, m[0], ranks[north], self.group))
-            if rs: ops.append(dist.P2POp(dist.isend, m[1], ranks[south], self.group))
-            if rn: ops.append(dist.P2POp(dist.irecv, m[2], ranks[south], self.group))
-            if rs: ops.append(dist.P2POp(dist.irecv, m[3], ranks[north], self.group))
+            hs, hr = (send.cpu(), self.torch.empty_like(recv, device="cpu")) if self._host_staged else (send, recv)
+            nn, ns = (s_north.numel() if rn else 0), (s_south.numel() if rs else 0)
+            if north == south:                                   # two ranks: both halves travel to the same peer
+                ops = [dist.P2POp(dist.isend, hs, ranks[north], self.group), dist.P2POp(dist.irecv, hr, ranks[north], self.group)]
+            else:
+                ops = []
+                if rn: ops.append(dist.P2POp(dist.isend, hs[:nn], ranks[north], self.group))
+                if rs: ops.append(dist.P2POp(dist.isend, hs[nn:nn+ns], ranks[south], self.group))
+                if rn: ops.append(dist.P2POp(dist.irecv, hr[:nn], ranks[south], self.group))
+                if rs: ops.append(dist.P2POp(dist.irecv, hr[nn:nn+ns], ranks[north], self.group))
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
             if self._host_staged:
-                r_south.copy_(m[2]); r_north.copy_(m[3])
-        self._ok(self.lib.mhh_halo_unpack_rows(self.G, arr, nf, rs, rn, r_south.data_ptr(), r_north.data_ptr(), self.stream))
+                recv.copy_(hr)
 
     def _halo2d(self, t):
         """One-time periodic ghost cells of a 2-D surface array (Boundary_cyclic::exec_2d, src/boundary_cyclic.cxx:445-500)."""
@@ -252,10 +264,16 @@ class HotPath:
         r_south, r_north = self.torch.empty_like(s_north), self.torch.empty_like(s_south)
         south, north = (self.rank - 1) % self.npy, (self.rank + 1) % self.npy
         ranks = dist.get_process_group_ranks(self.group) if self.group is not None else list(range(self.npy))
-        ops = [dist.P2POp(dist.isend, s_north, ranks[north], self.group), dist.P2POp(dist.isend, s_south, ranks[south], self.group),
-               dist.P2POp(dist.irecv, r_south, ranks[south], self.group), dist.P2POp(dist.irecv, r_north, ranks[north], self.group)]
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
+        if north == south:                                       # two ranks: one message pair, [northbound | southbound]
+            both, got = self.torch.cat([s_north, s_south]), self.torch.cat([r_south, r_north])
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, both, ranks[north], self.group), dist.P2POp(dist.irecv, got, ranks[north], self.group)]):
+                w.wait()
+            r_south, r_north = got[:g.jgc], got[g.jgc:]
+        else:
+            ops = [dist.P2POp(dist.isend, s_north, ranks[north], self.group), dist.P2POp(dist.isend, s_south, ranks[south], self.group),
+                   dist.P2POp(dist.irecv, r_south, ranks[south], self.group), dist.P2POp(dist.irecv, r_north, ranks[north], self.group)]
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
         t[:g.jgc] = r_south.to(t.device); t[g.jend:] = r_north.to(t.device)
 
     def cyclic_prognostic(self):

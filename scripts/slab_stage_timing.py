@@ -12,19 +12,8 @@ lib = capi.lib()
 hp = HotPath("drycblles", n, n, n, npy=npy, rank=0, group=None, global_init=None) if False else None
 # build the rank-0 object without a process group: construct with npy ranks but never call the exchanges
 class NoComm(HotPath):
-    def _exchange_ns(self, tensors, rows_south=None, rows_north=None):
-        arr = self._ptrs(tensors)
-        g, nf = self.grid, len(tensors)
-        rs = g.jgc if rows_south is None else rows_south
-        rn = g.jgc if rows_north is None else rows_north
-        key = (nf, rs, rn)
-        if key not in self._halo:
-            per_row = nf * g.kcells * g.icells
-            mk = lambda rows: torch.zeros(max(1, rows * per_row), device=self.device, dtype=self.td)
-            self._halo[key] = [mk(rs), mk(rn), mk(rn), mk(rs)]
-        s_south, s_north, r_south, r_north = self._halo[key]
-        self._ok(self.lib.mhh_halo_pack_rows(self.G, arr, nf, rs, rn, s_south.data_ptr(), s_north.data_ptr(), self.stream))
-        self._ok(self.lib.mhh_halo_unpack_rows(self.G, arr, nf, rs, rn, r_south.data_ptr(), r_north.data_ptr(), self.stream))
+    def _ring(self, *a):
+        pass
     def _halo2d(self, t):
         pass
     def _transpose(self):

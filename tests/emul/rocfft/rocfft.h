@@ -1,6 +1,6 @@
 // tests/emul/rocfft/rocfft.h -- TEST-ONLY stand-in for the slice of rocFFT that k_pres.hip uses, evaluated with a
 // plain O(n^2) DFT on host memory: batched 1-D/2-D real-to-hermitian and hermitian-to-real transforms on
-// contiguous data (the only layouts the library requests). Lets the pressure solver's own kernels
+// data with unit element stride, a row stride (2-D) and a batch distance as set by set_data_layout. Lets the pressure solver's own kernels
 // (input, column solves, unpack, output) be exercised on the CPU.
 #pragma once
 #include <cstddef>
@@ -12,19 +12,25 @@ enum rocfft_result_placement { rocfft_placement_inplace, rocfft_placement_notinp
 enum rocfft_transform_type { rocfft_transform_type_complex_forward, rocfft_transform_type_complex_inverse, rocfft_transform_type_real_forward, rocfft_transform_type_real_inverse };
 enum rocfft_precision { rocfft_precision_single, rocfft_precision_double };
 enum rocfft_array_type { rocfft_array_type_complex_interleaved, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved };
-struct rocfft_plan_t { rocfft_transform_type type; rocfft_precision prec; size_t nd, n0, n1, batch; };
+struct rocfft_plan_description_t { size_t is1 = 0, idist = 0, os1 = 0, odist = 0; };     // row stride / batch distance, 0 = contiguous
+typedef rocfft_plan_description_t* rocfft_plan_description;
+struct rocfft_plan_t { rocfft_transform_type type; rocfft_precision prec; size_t nd, n0, n1, batch; rocfft_plan_description_t lay; };
 typedef rocfft_plan_t* rocfft_plan;
-typedef int* rocfft_plan_description;
 struct rocfft_execution_info_t { void* load_fn = nullptr; void* load_data = nullptr; void* store_fn = nullptr; void* store_data = nullptr; };
 typedef rocfft_execution_info_t* rocfft_execution_info;
 inline rocfft_status rocfft_setup() { return rocfft_status_success; }
 inline rocfft_status rocfft_cleanup() { return rocfft_status_success; }
-inline rocfft_status rocfft_plan_description_create(rocfft_plan_description* d) { *d = new int(0); return rocfft_status_success; }
+inline rocfft_status rocfft_plan_description_create(rocfft_plan_description* d) { *d = new rocfft_plan_description_t(); return rocfft_status_success; }
 inline rocfft_status rocfft_plan_description_destroy(rocfft_plan_description d) { delete d; return rocfft_status_success; }
-inline rocfft_status rocfft_plan_description_set_data_layout(rocfft_plan_description, rocfft_array_type, rocfft_array_type, const size_t*, const size_t*,
-                                                             size_t, const size_t*, size_t, size_t, const size_t*, size_t) { return rocfft_status_success; }
-inline rocfft_status rocfft_plan_create(rocfft_plan* p, rocfft_result_placement, rocfft_transform_type t, rocfft_precision pr, size_t nd, const size_t* len, size_t batch, rocfft_plan_description)
-{ *p = new rocfft_plan_t{t, pr, nd, len[0], nd > 1 ? len[1] : 1, batch}; return rocfft_status_success; }
+inline rocfft_status rocfft_plan_description_set_data_layout(rocfft_plan_description d, rocfft_array_type, rocfft_array_type, const size_t*, const size_t*,
+                                                             size_t ins, const size_t* istr, size_t idist, size_t ons, const size_t* ostr, size_t odist)
+{
+    if ((ins && istr[0] != 1) || (ons && ostr[0] != 1)) return rocfft_status_failure;       // unit element stride only
+    d->is1 = ins > 1 ? istr[1] : 0; d->idist = idist; d->os1 = ons > 1 ? ostr[1] : 0; d->odist = odist;
+    return rocfft_status_success;
+}
+inline rocfft_status rocfft_plan_create(rocfft_plan* p, rocfft_result_placement, rocfft_transform_type t, rocfft_precision pr, size_t nd, const size_t* len, size_t batch, rocfft_plan_description d)
+{ *p = new rocfft_plan_t{t, pr, nd, len[0], nd > 1 ? len[1] : 1, batch, d ? *d : rocfft_plan_description_t()}; return rocfft_status_success; }
 inline rocfft_status rocfft_plan_destroy(rocfft_plan p) { delete p; return rocfft_status_success; }
 inline rocfft_status rocfft_execution_info_create(rocfft_execution_info* i) { *i = new rocfft_execution_info_t(); return rocfft_status_success; }
 // callbacks (k_pres.hip's fused form): Tdata load(Tdata*, size_t offset, void* cbdata, void*) / void store(Tdata*, size_t, Tdata, void*, void*)
@@ -45,6 +51,10 @@ inline void emul_fft_run(const rocfft_plan_t& P, void* in, void* out, const rocf
     const store_t scb = info ? reinterpret_cast<store_t>(info->store_fn) : nullptr;
     typedef std::complex<double> cd;
     const size_t n0 = P.n0, n1 = P.n1, nh = n0/2+1;
+    const bool fwd_r = (P.type == rocfft_transform_type_real_forward);
+    // hermitian side: row pitch and batch distance (real side and complex transforms: contiguous, checked below)
+    const size_t hp = fwd_r ? (P.lay.os1 ? P.lay.os1 : nh) : (P.lay.is1 ? P.lay.is1 : nh);
+    const size_t hd = fwd_r ? (P.lay.odist ? P.lay.odist : nh*n1) : (P.lay.idist ? P.lay.idist : nh*n1);
     const double pi = std::acos(-1.0);
     for (size_t b=0; b<P.batch; ++b)
     {
@@ -68,23 +78,23 @@ inline void emul_fft_run(const rocfft_plan_t& P, void* in, void* out, const rocf
             std::vector<T> rin;
             if (lcb) { rin.resize(n0*n1); for (size_t e=0; e<n0*n1; ++e) rin[e] = lcb(static_cast<T*>(in), b*n0*n1 + e, info->load_data, nullptr); }
             const T* r = lcb ? rin.data() : static_cast<const T*>(in) + b*n0*n1;
-            std::complex<T>* h = static_cast<std::complex<T>*>(out) + b*nh*n1;
+            std::complex<T>* h = static_cast<std::complex<T>*>(out) + b*hd;
             for (size_t ky=0; ky<n1; ++ky) for (size_t kx=0; kx<nh; ++kx)
             {
                 cd acc = 0;
                 for (size_t j=0; j<n1; ++j) for (size_t i=0; i<n0; ++i)
                     acc += (double)r[i + j*n0] * std::polar(1.0, -2*pi*((double)((kx*i) % n0)/n0 + (double)((ky*j) % n1)/n1));
-                h[kx + ky*nh] = std::complex<T>((T)acc.real(), (T)acc.imag());
+                h[kx + ky*hp] = std::complex<T>((T)acc.real(), (T)acc.imag());
             }
         }
         else
         {
-            const std::complex<T>* h = static_cast<const std::complex<T>*>(in) + b*nh*n1;
+            const std::complex<T>* h = static_cast<const std::complex<T>*>(in) + b*hd;
             T* r = static_cast<T*>(out) + b*n0*n1;
             for (size_t ky=0; ky<n1; ++ky) for (size_t kx=0; kx<n0; ++kx)
             {
-                if (kx < nh) full[kx + ky*n0] = cd(h[kx + ky*nh].real(), h[kx + ky*nh].imag());
-                else { const size_t mx = n0-kx, my = (n1-ky) % n1; full[kx + ky*n0] = std::conj(cd(h[mx + my*nh].real(), h[mx + my*nh].imag())); }
+                if (kx < nh) full[kx + ky*n0] = cd(h[kx + ky*hp].real(), h[kx + ky*hp].imag());
+                else { const size_t mx = n0-kx, my = (n1-ky) % n1; full[kx + ky*n0] = std::conj(cd(h[mx + my*hp].real(), h[mx + my*hp].imag())); }
             }
             for (size_t j=0; j<n1; ++j) for (size_t i=0; i<n0; ++i)
             {
