@@ -238,6 +238,22 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
     // carried bottom-face products: advective centred (T) and upwind (G) parts, diffusive flux (D)
     TF cTu = 0, cGu = 0, cDu = 0, cTv = 0, cGv = 0, cDv = 0, cTw = 0, cGw = 0, cDw = 0, cTs = 0, cGs = 0, cDs = 0;
 
+    // Latency of the tendency read-modify-writes (fp64 form; the fp32 form has no registers to spare at four waves per SIMD):
+    //  * TPREF: the tendencies of the NEXT level are loaded a whole level ahead of their use, like the LDS-DMA planes;
+    //  * DSTORE: the last tendency finished in a level (the scalar's) is stored at the top of the next level, so that the
+    //    s_waitcnt vmcnt(0) in front of the barrier -- which on gfx9 also waits for stores -- does not find it just issued.
+    //    (1: all four deferred -- spills; 2: w and scalar; 3: scalar only.)
+    // 512^3: 6.05 -> 5.75 (TPREF) -> 5.67 ms (DSTORE 3), 225 -> 245 VGPRs, still two waves per SIMD and no scratch.
+#ifndef MHH_MARCH_TPREF
+#define MHH_MARCH_TPREF 1
+#endif
+#ifndef MHH_MARCH_DSTORE
+#define MHH_MARCH_DSTORE 3
+#endif
+    constexpr bool TPREF = (sizeof(TF) == 8) && (MHH_MARCH_TPREF != 0);
+    constexpr int DSTORE = (sizeof(TF) == 8) ? MHH_MARCH_DSTORE : 0;       // 0: every store where its value is finished
+    TF dsu = 0, dsv = 0, dsw = 0, dss = 0; int dsk = -1; bool dsw_on = false;
+    TF tpu = 0, tpv = 0, tpw = 0, tps = 0;
     const TF dxi = g.dxi_t, dyi = g.dyi_t;          // advection spelling TF(1.)/dx
     const TF dxd = g.dxi_d, dyd = g.dyi_d;          // diffusion spelling TF(1./dx)
     const TF visc = f.visc;
@@ -274,6 +290,17 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
         }
         const TF nu = more ? colval(f.u, k+4) : TF(0), nv = more ? colval(f.v, k+4) : TF(0), nw = more ? colval(f.w, k+4) : TF(0);
         const TF ns = (more && HAS_S) ? colval(f.s, k+4) : TF(0);
+        if (DSTORE && dsk >= 0 && active)
+        {
+            const int cd = col + dsk*kk;
+            if (DSTORE == 1) { f.ut[cd] = dsu; f.vt[cd] = dsv; }
+            if (DSTORE <= 2 && dsw_on) f.wt[cd] = dsw;
+            if (HAS_S) f.st[cd] = dss;
+        }
+        dsk = -1;
+        const TF tcu = tpu, tcv = tpv, tcw = tpw, tcs = tps;      // this level's tendencies (loaded during the previous level)
+        if (TPREF && more && active) {     // the warm-up level ks = kb-1 fetches those of kb
+            const int cn = col + (k+1)*kk; tpu = f.ut[cn]; tpv = f.vt[cn]; tpw = f.wt[cn]; if (HAS_S) tps = f.st[cn]; }
 
         const TF* __restrict__ uk = U[slot(k, RU)] + l;  const TF* __restrict__ ukm = U[slot(k-1, RU)] + l;
         const TF* __restrict__ vk = V[slot(k, RU)] + l;  const TF* __restrict__ vkm = V[slot(k-1, RU)] + l;
@@ -342,7 +369,7 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
             {   // u
                 const TF ue = i2(uk[0], uk[1]), uwf = i2(uk[-1], uk[0]);
                 const TF vn = i2(vk[TI-1], vk[TI]), vs = i2(vk[-1], vk[0]);
-                TF t = f.ut[c];
+                TF t = TPREF ? tcu : f.ut[c];
                 t += advec25_hor(uk, 0, TI, ue, uwf, vn, vs, dxi, dyi);
                 t += vert_combine(otc, obc, Tu, cTu, Gu, cGu, rk, rk1, dzi);
                 const TF ee = ek[0] + visc, ew = ek[-1] + visc;
@@ -356,12 +383,13 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
                 else if (ft) ver = div_rho( - rhkp * f.uft[ij] - cDu, rk, rk1 ) * dzi;
                 else         ver = div_rho( Du - cDu, rk, rk1 ) * dzi;
                 t += hor + ver;
-                f.ut[c] = t;
+                dsk = k;
+                if (DSTORE == 1) dsu = t; else f.ut[c] = t;
             }
             {   // v
                 const TF ue = i2(uk[1-TI], uk[1]), uwf = i2(uk[-TI], uk[0]);
                 const TF vn = i2(vk[0], vk[TI]), vs = i2(vk[-TI], vk[0]);
-                TF t = f.vt[c];
+                TF t = TPREF ? tcv : f.vt[c];
                 t += advec25_hor(vk, 0, TI, ue, uwf, vn, vs, dxi, dyi);
                 t += vert_combine(otc, obc, Tv, cTv, Gv, cGv, rk, rk1, dzi);
                 const TF ee = TF(0.25)*(ek[-TE  ] + ek[0 ] + ek[1-TE] + ek[1]) + visc;
@@ -375,13 +403,14 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
                 else if (ft) ver = div_rho( - rhkp * f.vft[ij] - cDv, rk, rk1 ) * dzi;
                 else         ver = div_rho( Dv - cDv, rk, rk1 ) * dzi;
                 t += hor + ver;
-                f.vt[c] = t;
+                if (DSTORE == 1) dsv = t; else f.vt[c] = t;
             }
+            dsw_on = (FAST || k > g.kstart);
             if (FAST || k > g.kstart)
             {   // w
                 const TF ue = i2(ukm[1], uk[1]), uwf = i2(ukm[0], uk[0]);
                 const TF vn = i2(vkm[TI], vk[TI]), vs = i2(vkm[0], vk[0]);
-                TF t = f.wt[c];
+                TF t = TPREF ? tcw : f.wt[c];
                 if (HAS_S && f.threfh) { const TF th_k = f.threfh[k]; t += f.grav/th_k * (i2(sw[2], sw[3]) - th_k); }   // src/thermo_dry.cxx:165-178
                 t += advec25_hor(wk, 0, TI, ue, uwf, vn, vs, dxi, dyi);
                 t += vert_combine(otw, obw, Tw, cTw, Gw, cGw, rhk, rhk1, dzhi);
@@ -394,11 +423,11 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
                      + ( en*((wk[TI]-wk[0  ])*dyd + (vk[TI]-vkm[TI])*dzhi)
                        - es*((wk[0 ]-wk[-TI])*dyd + (vk[0 ]-vkm[0 ])*dzhi) ) * dyd
                      + div_rho( Dw - cDw, rhk, rhk1 ) * TF(2.)*dzhi;
-                f.wt[c] = t;
+                if (DSTORE == 1 || DSTORE == 2) dsw = t; else f.wt[c] = t;
             }
             if (HAS_S)
             {   // scalar
-                TF t = f.st[c];
+                TF t = TPREF ? tcs : f.st[c];
                 t += advec25_hor(sk, 0, TI, uk[1], uk[0], vk[TI], vk[0], dxi, dyi);
                 t += vert_combine(otc, obc, Ts, cTs, Gs, cGs, rk, rk1, dzi);
                 const TF ee = TF(0.5)*(ek[0  ]+ek[1 ])/f.tPr + f.svisc;
@@ -412,7 +441,7 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
                 else if (ft) ver = div_rho( -rhkp * f.sft[ij] - cDs, rk, rk1 ) * dzi;
                 else         ver = div_rho( Ds - cDs, rk, rk1 ) * dzi;
                 t += hor + ver;
-                f.st[c] = t;
+                if (DSTORE) dss = t; else f.st[c] = t;
             }
         }
         STAMP(3);
@@ -457,6 +486,13 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
             level(k, std::false_type{}, std::false_type{});       // fp32: one body (127 VGPRs, 3-4 waves per SIMD); four bodies cost it a wave
         else if (rho_one) { if (fast) level(k, std::true_type{}, std::true_type{});  else level(k, std::false_type{}, std::true_type{}); }
         else              { if (fast) level(k, std::true_type{}, std::false_type{}); else level(k, std::false_type{}, std::false_type{}); }
+    }
+    if (DSTORE && dsk >= 0 && active)
+    {
+        const int cd = col + dsk*kk;
+        if (DSTORE == 1) { f.ut[cd] = dsu; f.vt[cd] = dsv; }
+        if (DSTORE <= 2 && dsw_on) f.wt[cd] = dsw;
+        if (HAS_S) f.st[cd] = dss;
     }
 #ifdef MHH_MARCH_STAMPS
     if ((threadIdx.x & 63) == 0) for (int n=0; n<8; ++n) atomicAdd(&g_march_stamps[n], stamp_acc[n]);

@@ -107,12 +107,21 @@ __global__ void __launch_bounds__(64*NJ, MHH_MARCH4_OCC) rhs44_march_kernel(cons
 
     // the u and v results of level k are stored at the top of iteration k+1: the s_waitcnt vmcnt(0) in front of the
     // end-of-level barrier also waits for stores, and stores issued right before it would expose their latency
+    // ... and the tendencies themselves are read one level ahead of their use (MHH_MARCH4_TPREF=0: where they are used)
+#ifndef MHH_MARCH4_TPREF
+#define MHH_MARCH4_TPREF 1
+#endif
+    constexpr bool TPREF = (MHH_MARCH4_TPREF != 0);
     TF ut_pending = 0, vt_pending = 0; int c_pending = -1;
+    TF tnu = 0, tnv = 0, tnw = 0;
+    if (TPREF && active && kb < ke) { const int c0 = col + kb*kk; tnu = f.ut[c0]; tnv = f.vt[c0]; tnw = f.wt[c0]; }
     for (int k = kb; k < ke; ++k)
     {
         const bool more = (k + 1 < ke);
         if (more) dma_tile(f.w, k+3, W[sw(k+3)]);
         if (c_pending >= 0) { f.ut[c_pending] = ut_pending; f.vt[c_pending] = vt_pending; c_pending = -1; }
+        const TF tcu = tnu, tcv = tnv, tcw = tnw;
+        if (TPREF && more && active) { const int cn = col + (k+1)*kk; tnu = f.ut[cn]; tnv = f.vt[cn]; tnw = f.wt[cn]; }
         const TF nu = more ? colval(f.u, k+4) : TF(0), nv = more ? colval(f.v, k+4) : TF(0), nw = more ? colval(f.w, k+4) : TF(0);
 
         const MarchView<TF, TI> Uv{{U[su(k-2)]+l, U[su(k-1)]+l, U[su(k)]+l, U[su(k+1)]+l, nullptr}, uw};
@@ -129,7 +138,7 @@ __global__ void __launch_bounds__(64*NJ, MHH_MARCH4_OCC) rhs44_march_kernel(cons
             const TF gw4[4] = {g.dzi4[k-2], g.dzi4[k-1], g.dzi4[k], g.dzi4[k+1]};
             advec4_mom_v<2>(ad, Wv, Uv, Vv, Wv, botw, top, dxi, dyi, g.dzhi4[k], dim3);
             diff4_v(df, Wv, botw, top, f.visc, g.dxidxi_t, g.dyidyi_t, gw4, g.dzhi4[k], dim3);
-            f.wt[c] = both(f.wt[c], ad, df);
+            f.wt[c] = both(TPREF ? tcw : f.wt[c], ad, df);
         }
         if (more)
         {
@@ -142,10 +151,10 @@ __global__ void __launch_bounds__(64*NJ, MHH_MARCH4_OCC) rhs44_march_kernel(cons
             const TF gc4[4] = {g.dzhi4[k-1], g.dzhi4[k], g.dzhi4[k+1], g.dzhi4[k+2]};
             advec4_mom_v<0>(ad, Uv, Uv, Vv, Wv, bot, top, dxi, dyi, g.dzi4[k], dim3);
             diff4_v(df, Uv, bot, top, f.visc, g.dxidxi_d, g.dyidyi_d, gc4, g.dzi4[k], dim3);
-            ut_pending = both(f.ut[c], ad, df);
+            ut_pending = both(TPREF ? tcu : f.ut[c], ad, df);
             advec4_mom_v<1>(ad, Vv, Uv, Vv, Wv, bot, top, dxi, dyi, g.dzi4[k], dim3);
             diff4_v(df, Vv, bot, top, f.visc, g.dxidxi_d, g.dyidyi_d, gc4, g.dzi4[k], dim3);
-            vt_pending = both(f.vt[c], ad, df);
+            vt_pending = both(TPREF ? tcv : f.vt[c], ad, df);
             c_pending = c;
         }
         if (more)
