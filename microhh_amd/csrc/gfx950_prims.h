@@ -7,18 +7,72 @@ namespace mhh
 // Asynchronous global -> LDS copy of 16 bytes per lane (global_load_lds_dwordx4): every active lane supplies its own
 // global address; the data lands at `lds_wave_base + lane*16` (a wave-uniform base, contiguous by lane -- not a
 // per-lane scatter). No VGPR is written; completion is tracked by vmcnt.
-__device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_wave_base)
+//
+// Issued as inline asm, not through __builtin_amdgcn_global_load_lds: the compiler models the builtin as a store to LDS
+// that any later ds_read may alias (the ring slot is a run-time index), so it puts an s_waitcnt vmcnt(0) in front of the
+// first LDS read after the copy was issued -- the copy of the NEXT plane then never overlaps the compute on the current
+// ones, which is the whole point of the ring. Here the ordering is the kernels' own: a copy is issued after the barrier
+// that retires the slot's last readers, and wait_vmem() + barrier stand between the copy and the slot's first reader.
+// RAW = false is the builtin form. The fp64 kernels take RAW (2i5+smag2 -1.5 %, advec_4+diff_4 -10 % at 512x256x256);
+// the fp32 kernels, at four waves per SIMD, measured 11 % SLOWER with it (gabls1 1024x1024x256) and keep the builtin.
+// (-DMHH_DMA_BUILTIN forces the builtin everywhere for A/B runs.)
+__device__ __forceinline__ unsigned lds_address(void* lds_wave_base)
 {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+    return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_wave_base);
+}
+template<bool RAW> __device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_wave_base)
+{
+#ifdef MHH_DMA_BUILTIN
+    constexpr bool raw = false;
+#else
+    constexpr bool raw = RAW;
+#endif
+    if constexpr (!raw)
+    {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                         (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+    }
+    else
+    {
+        unsigned m0_saved;     // m0 is a reserved register: put back what the compiler may have parked there
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(m0_saved) : "v"(gsrc), "s"(lds_address(lds_wave_base)) : "memory");
+    }
 }
 // The 4-byte form (global_load_lds_dword): data lands at `lds_wave_base + lane*4`; needs 4-byte alignment only.
-__device__ __forceinline__ void lds_dma4(const void* gsrc, void* lds_wave_base)
+template<bool RAW> __device__ __forceinline__ void lds_dma4(const void* gsrc, void* lds_wave_base)
 {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+#ifdef MHH_DMA_BUILTIN
+    constexpr bool raw = false;
+#else
+    constexpr bool raw = RAW;
+#endif
+    if constexpr (!raw)
+    {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                         (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+    }
+    else
+    {
+        unsigned m0_saved;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(m0_saved) : "v"(gsrc), "s"(lds_address(lds_wave_base)) : "memory");
+    }
+}
+// Load of a wave-uniform element of a read-only table (per-level metrics, base-state profiles) through the constant
+// address space, i.e. as an s_load on the scalar cache, tracked by lgkmcnt. A plain load of such an element inside a loop
+// that also stores is emitted as a VECTOR load (the compiler cannot prove the table is not clobbered), and its
+// s_waitcnt vmcnt(0) then also waits for every LDS-DMA copy and prefetch in flight -- the latency the marching kernels
+// are built to hide. Only for memory that no thread writes during the kernel (the scalar cache is not coherent with stores).
+template<class T> __device__ __forceinline__ T uniform_load(const T* table, int idx)
+{
+    typedef const T __attribute__((address_space(4)))* const_ptr;
+    return ((const_ptr)(table))[idx];
 }
 // Wait until all of this wave's vector-memory operations (loads, stores, LDS-DMA) have completed. Inline asm on
 // purpose: the compiler may not elide or move it (MI355X_MICROARCH.md, "Compiler hazard").
-__device__ __forceinline__ void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// The builtin behind it (s_waitcnt vmcnt(0), other counters untouched) tells the compiler's own wait-count bookkeeping
+// the same thing: without it, values loaded in one loop iteration and first used in the next (the prefetched tendencies)
+// get a compiler-inserted vmcnt(0) at that use -- AFTER the next level's copies have been issued, draining them.
+__device__ __forceinline__ void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_waitcnt(0x0F70); }
 }

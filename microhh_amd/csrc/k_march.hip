@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
     };
     // LDS-DMA movers: PB bytes per lane straight into the ring slot; lanes outside the tile / the array sit out
     const int wave_e0 = tid & ~63;                                    // first piece index of this wave within a sweep
-    auto dma_piece = [](const uint32_t* src, uint32_t* dst) { if constexpr (PB == 16) lds_dma16(src, dst); else lds_dma4(src, dst); };
+    auto dma_piece = [](const uint32_t* src, uint32_t* dst) { if constexpr (PB == 16) lds_dma16<(sizeof(TF) == 8)>(src, dst); else lds_dma4<(sizeof(TF) == 8)>(src, dst); };
     auto dma_tile = [&](const TF* __restrict__ fld, int kp, TF* __restrict__ lds)
     {
         if (kp < 0 || kp >= g.kcells) return;                         // wave-uniform
@@ -308,8 +308,9 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
         const TF* __restrict__ sk = S[HAS_S ? slot(k, RS) : 0] + (HAS_S ? l : 0);
         const TF* __restrict__ ek = E[slot(k, RE)] + le; const TF* __restrict__ ekm = E[slot(k-1, RE)] + le; const TF* __restrict__ ekp = E[slot(k+1, RE)] + le;
         // per-level coefficients (wave-uniform)
-        const TF rhkp = f.rhorefh[k+1], rhk = f.rhorefh[k], rk = f.rhoref[k];
-        const TF dzi = g.dzi[k], dzhi = g.dzhi[k], dzhip = g.dzhi[k+1];
+        // per-level coefficients: scalar loads (uniform_load), not vector loads whose wait would drain the copies in flight
+        const TF rhkp = RHO1 ? TF(1) : uniform_load(f.rhorefh, k+1), rhk = RHO1 ? TF(1) : uniform_load(f.rhorefh, k), rk = RHO1 ? TF(1) : uniform_load(f.rhoref, k);
+        const TF dzi = uniform_load(g.dzi, k), dzhi = uniform_load(g.dzhi, k), dzhip = uniform_load(g.dzhi, k+1);
         const bool rk1 = RHO1 || (rk == TF(1.)), rhk1 = RHO1 || (rhk == TF(1.));
         const int otc = FAST ? 6 : order_face_c(k+1, g.kstart, g.kend);
         const int obc = FAST ? 6 : order_face_c(k, g.kstart, g.kend);
@@ -411,7 +412,7 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
                 const TF ue = i2(ukm[1], uk[1]), uwf = i2(ukm[0], uk[0]);
                 const TF vn = i2(vkm[TI], vk[TI]), vs = i2(vkm[0], vk[0]);
                 TF t = TPREF ? tcw : f.wt[c];
-                if (HAS_S && f.threfh) { const TF th_k = f.threfh[k]; t += f.grav/th_k * (i2(sw[2], sw[3]) - th_k); }   // src/thermo_dry.cxx:165-178
+                if (HAS_S && f.threfh) { const TF th_k = uniform_load(f.threfh, k); t += f.grav/th_k * (i2(sw[2], sw[3]) - th_k); }   // src/thermo_dry.cxx:165-178
                 t += advec25_hor(wk, 0, TI, ue, uwf, vn, vs, dxi, dyi);
                 t += vert_combine(otw, obw, Tw, cTw, Gw, cGw, rhk, rhk1, dzhi);
                 const TF ee = TF(0.25)*(ekm[0  ] + ek[0  ] + ekm[1 ] + ek[1 ]) + visc;
@@ -447,16 +448,18 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
         STAMP(3);
         // ---- carry the top faces down, rotate the rings, shift the windows --------------------------------------------
         cTu = Tu; cGu = Gu; cDu = Du; cTv = Tv; cGv = Gv; cDv = Dv; cTw = Tw; cGw = Gw; cDw = Dw; cTs = Ts; cGs = Gs; cDs = Ds;
+        if constexpr (DMA)
+        {
+            // unconditional (also after the chunk's last level, where nothing is in flight): every path back to the loop head
+            // then carries a vmcnt(0) the compiler can see, and it inserts no wait of its own in the next level
+            wait_vmem();                                           // this wave's copies have landed (and its stores have left)
+            STAMP(4);
+            __syncthreads();                                       // ... everyone's have, and everyone is done with the oldest planes
+            STAMP(6);
+        }
         if (more)
         {
-            if constexpr (DMA)
-            {
-                wait_vmem();                                       // this wave's copies have landed (and its stores have left)
-                STAMP(4);
-                __syncthreads();                                   // ... everyone's have, and everyone is done with the oldest planes
-                STAMP(6);
-            }
-            else
+            if constexpr (!DMA)
             {
                 __syncthreads();                                   // everyone is done reading the planes that are about to be replaced
                 STAMP(4);

@@ -93,6 +93,14 @@ __global__ void __launch_bounds__(64*NJ, MHH_MARCH4_OCC) rhs44_march_kernel(cons
     TF uw[7], vw[7], ww[7];
 #pragma unroll
     for (int n=0; n<7; ++n) { uw[n] = colval(f.u, kb-3+n); vw[n] = colval(f.v, kb-3+n); ww[n] = colval(f.w, kb-3+n); }
+    // The tendencies are read one level ahead of their use (MHH_MARCH4_TPREF=0: where they are used); those of the first
+    // level here, ahead of the prologue's wait, so that no load is pending when the loop is entered.
+#ifndef MHH_MARCH4_TPREF
+#define MHH_MARCH4_TPREF 1
+#endif
+    constexpr bool TPREF = (MHH_MARCH4_TPREF != 0);
+    TF tnu = 0, tnv = 0, tnw = 0;
+    if (TPREF && active && kb < ke) { const int c0 = col + kb*kk; tnu = f.ut[c0]; tnv = f.vt[c0]; tnw = f.wt[c0]; }
     wait_vmem();
     __syncthreads();
 
@@ -107,14 +115,7 @@ __global__ void __launch_bounds__(64*NJ, MHH_MARCH4_OCC) rhs44_march_kernel(cons
 
     // the u and v results of level k are stored at the top of iteration k+1: the s_waitcnt vmcnt(0) in front of the
     // end-of-level barrier also waits for stores, and stores issued right before it would expose their latency
-    // ... and the tendencies themselves are read one level ahead of their use (MHH_MARCH4_TPREF=0: where they are used)
-#ifndef MHH_MARCH4_TPREF
-#define MHH_MARCH4_TPREF 1
-#endif
-    constexpr bool TPREF = (MHH_MARCH4_TPREF != 0);
     TF ut_pending = 0, vt_pending = 0; int c_pending = -1;
-    TF tnu = 0, tnv = 0, tnw = 0;
-    if (TPREF && active && kb < ke) { const int c0 = col + kb*kk; tnu = f.ut[c0]; tnv = f.vt[c0]; tnw = f.wt[c0]; }
     for (int k = kb; k < ke; ++k)
     {
         const bool more = (k + 1 < ke);
@@ -135,9 +136,9 @@ __global__ void __launch_bounds__(64*NJ, MHH_MARCH4_OCC) rhs44_march_kernel(cons
         if (active && k > g.kstart)
         {
             const bool botw = (k == g.kstart+1);
-            const TF gw4[4] = {g.dzi4[k-2], g.dzi4[k-1], g.dzi4[k], g.dzi4[k+1]};
-            advec4_mom_v<2>(ad, Wv, Uv, Vv, Wv, botw, top, dxi, dyi, g.dzhi4[k], dim3);
-            diff4_v(df, Wv, botw, top, f.visc, g.dxidxi_t, g.dyidyi_t, gw4, g.dzhi4[k], dim3);
+            const TF gw4[4] = {uniform_load(g.dzi4, k-2), uniform_load(g.dzi4, k-1), uniform_load(g.dzi4, k), uniform_load(g.dzi4, k+1)};
+            advec4_mom_v<2>(ad, Wv, Uv, Vv, Wv, botw, top, dxi, dyi, uniform_load(g.dzhi4, k), dim3);
+            diff4_v(df, Wv, botw, top, f.visc, g.dxidxi_t, g.dyidyi_t, gw4, uniform_load(g.dzhi4, k), dim3);
             f.wt[c] = both(TPREF ? tcw : f.wt[c], ad, df);
         }
         if (more)
@@ -148,21 +149,18 @@ __global__ void __launch_bounds__(64*NJ, MHH_MARCH4_OCC) rhs44_march_kernel(cons
         // ---- u and v equations (planes k of u, v; k-1..k+2 of w) --------------------------------------------------------
         if (active)
         {
-            const TF gc4[4] = {g.dzhi4[k-1], g.dzhi4[k], g.dzhi4[k+1], g.dzhi4[k+2]};
-            advec4_mom_v<0>(ad, Uv, Uv, Vv, Wv, bot, top, dxi, dyi, g.dzi4[k], dim3);
-            diff4_v(df, Uv, bot, top, f.visc, g.dxidxi_d, g.dyidyi_d, gc4, g.dzi4[k], dim3);
+            const TF gc4[4] = {uniform_load(g.dzhi4, k-1), uniform_load(g.dzhi4, k), uniform_load(g.dzhi4, k+1), uniform_load(g.dzhi4, k+2)};
+            advec4_mom_v<0>(ad, Uv, Uv, Vv, Wv, bot, top, dxi, dyi, uniform_load(g.dzi4, k), dim3);
+            diff4_v(df, Uv, bot, top, f.visc, g.dxidxi_d, g.dyidyi_d, gc4, uniform_load(g.dzi4, k), dim3);
             ut_pending = both(TPREF ? tcu : f.ut[c], ad, df);
-            advec4_mom_v<1>(ad, Vv, Uv, Vv, Wv, bot, top, dxi, dyi, g.dzi4[k], dim3);
-            diff4_v(df, Vv, bot, top, f.visc, g.dxidxi_d, g.dyidyi_d, gc4, g.dzi4[k], dim3);
+            advec4_mom_v<1>(ad, Vv, Uv, Vv, Wv, bot, top, dxi, dyi, uniform_load(g.dzi4, k), dim3);
+            diff4_v(df, Vv, bot, top, f.visc, g.dxidxi_d, g.dyidyi_d, gc4, uniform_load(g.dzi4, k), dim3);
             vt_pending = both(TPREF ? tcv : f.vt[c], ad, df);
             c_pending = c;
         }
-        if (more)
-        {
-            wait_vmem();
-            __syncthreads();
-            shift7(uw, nu); shift7(vw, nv); shift7(ww, nw);
-        }
+        wait_vmem();                  // unconditional: every path back to the loop head carries a vmcnt(0) the compiler can see
+        __syncthreads();
+        if (more) { shift7(uw, nu); shift7(vw, nv); shift7(ww, nw); }
     }
     if (c_pending >= 0) { f.ut[c_pending] = ut_pending; f.vt[c_pending] = vt_pending; }
 }

@@ -81,8 +81,8 @@ struct TileCopy
         for (int n=0; n<NLD; ++n)
             if (ok[n])
             {
-                if constexpr (PB == 16) lds_dma16(pl + off[n], dst + (size_t)(wave_e0 + n*NT)*PW);
-                else                    lds_dma4 (pl + off[n], dst + (size_t)(wave_e0 + n*NT)*PW);
+                if constexpr (PB == 16) lds_dma16<(sizeof(TF) == 8)>(pl + off[n], dst + (size_t)(wave_e0 + n*NT)*PW);
+                else                    lds_dma4<(sizeof(TF) == 8)>(pl + off[n], dst + (size_t)(wave_e0 + n*NT)*PW);
             }
     }
 };

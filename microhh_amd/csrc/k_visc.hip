@@ -32,7 +32,9 @@ template<class TF> struct ViscFields
 #ifndef MHH_VISC_KC
 #define MHH_VISC_KC 64
 #endif
-template<class TF, int NJ, int PB>
+// EXT_N2: N2 comes from a caller-supplied 3-D field instead of th. Its own instantiation, so that the usual form has no
+// vector load (and hence no compiler-placed s_waitcnt vmcnt(0), which would also wait for the plane copies) inside a level.
+template<class TF, int NJ, int PB, bool EXT_N2>
 __global__ void __launch_bounds__(64*NJ, MHH_VISC_OCC) visc_march_kernel(const GridDev<TF> g, const ViscFields<TF> f, const MarchTiling mt)
 {
     constexpr int TI = 72, TJ = NJ + 2, NT = 64*NJ, NTILE = TI*TJ;    // tile x from i0-ex (ex <= 4: 64 + ex + 1 <= 72)
@@ -71,6 +73,11 @@ __global__ void __launch_bounds__(64*NJ, MHH_VISC_OCC) visc_march_kernel(const G
         dma_tile(f.u, p, U[slot(p)]); dma_tile(f.v, p, V[slot(p)]); dma_tile(f.w, p, W[slot(p)]);
     }
     TF thm = colth(ks-1), thc = colth(ks), thp = colth(ks+1);         // th at k-1, k, k+1 of this column
+    // the 2-D surface inputs of this column, once, ahead of the prologue's wait: a load inside the loop is followed by an
+    // s_waitcnt vmcnt(0) at its use, which would also wait for the plane copies just issued
+    const bool surf = f.sm && (kb == g.kstart);
+    const TF z0m_c = f.sm ? f.z0m[ij] : TF(0);
+    const TF dudz_c = surf ? f.dudz[ij] : TF(0), dvdz_c = surf ? f.dvdz[ij] : TF(0), dbdz_c = (surf && !f.neutral) ? f.dbdz[ij] : TF(0);
     wait_vmem();
     __syncthreads();
 
@@ -91,7 +98,7 @@ __global__ void __launch_bounds__(64*NJ, MHH_VISC_OCC) visc_march_kernel(const G
         const TF* __restrict__ uk = U[slot(k)] + l;  const TF* __restrict__ ukp = U[slot(k+1)] + l;
         const TF* __restrict__ vk = V[slot(k)] + l;  const TF* __restrict__ vkp = V[slot(k+1)] + l;
         const TF* __restrict__ wk = W[slot(k)] + l;  const TF* __restrict__ wkp = W[slot(k+1)] + l;
-        const TF dzhip = g.dzhi[k+1];
+        const TF dzhip = uniform_load(g.dzhi, k+1);
 
         // top-face shear terms of level k == bottom-face terms of level k+1 (src/diff_smag2.cxx:140-141,146-147 vs :138-139,144-145)
         const TF tu0 = TF(0.125)*sq((ukp[0 ]-uk[0 ])*dzhip + (wkp[0 ]-wkp[-1 ])*dxi);
@@ -104,19 +111,19 @@ __global__ void __launch_bounds__(64*NJ, MHH_VISC_OCC) visc_march_kernel(const G
             const bool mo = f.sm && (k == g.kstart);
             TF acc = sq((uk[1]-uk[0])*dxi);
             acc = acc + sq((vk[TI]-vk[0])*dyi);
-            acc = acc + sq((wkp[0]-wk[0])*g.dzi[k]);
+            acc = acc + sq((wkp[0]-wk[0])*uniform_load(g.dzi, k));
             acc = acc + TF(0.125)*sq((uk[0    ]-uk[-TI  ])*dyi + (vk[0   ]-vk[-1   ])*dxi);
             acc = acc + TF(0.125)*sq((uk[1    ]-uk[1-TI ])*dyi + (vk[1   ]-vk[0    ])*dxi);
             acc = acc + TF(0.125)*sq((uk[TI   ]-uk[0    ])*dyi + (vk[TI  ]-vk[TI-1 ])*dxi);
             acc = acc + TF(0.125)*sq((uk[1+TI ]-uk[1    ])*dyi + (vk[1+TI]-vk[TI   ])*dxi);
             if (mo)
             {   // unresolved wall: MOST gradients replace the resolved du/dz, dv/dz (src/diff_smag2.cxx:72-114)
-                acc = acc + TF(0.5)*sq(f.dudz[ij]);
+                acc = acc + TF(0.5)*sq(dudz_c);
                 acc = acc + TF(0.125)*sq((wk [0 ]-wk [-1 ])*dxi);
                 acc = acc + TF(0.125)*sq((wk [1 ]-wk [0  ])*dxi);
                 acc = acc + TF(0.125)*sq((wkp[0 ]-wkp[-1 ])*dxi);
                 acc = acc + TF(0.125)*sq((wkp[1 ]-wkp[0  ])*dxi);
-                acc = acc + TF(0.5)*sq(f.dvdz[ij]);
+                acc = acc + TF(0.5)*sq(dvdz_c);
                 acc = acc + TF(0.125)*sq((wk [0 ]-wk [-TI])*dyi);
                 acc = acc + TF(0.125)*sq((wk [TI]-wk [0  ])*dyi);
                 acc = acc + TF(0.125)*sq((wkp[0 ]-wkp[-TI])*dyi);
@@ -133,20 +140,17 @@ __global__ void __launch_bounds__(64*NJ, MHH_VISC_OCC) visc_march_kernel(const G
             TF n2 = TF(0);
             if (!f.neutral)
             {
-                if (mo) n2 = f.dbdz[ij];
-                else if (f.N2) n2 = f.N2[c];
-                else n2 = f.grav/f.thref[k]*TF(0.5)*(thp - thm)*g.dzi[k];
+                if (mo) n2 = dbdz_c;
+                else if (EXT_N2) n2 = f.N2[c];
+                else n2 = f.grav/uniform_load(f.thref, k)*TF(0.5)*(thp - thm)*uniform_load(g.dzi, k);
             }
             c_pending = c;
-            ev_pending = evisc_value(s2, n2, f.sm, f.neutral, f.mlen0[k], f.sm ? g.z[k] : TF(0), f.sm ? f.z0m[ij] : TF(0), f.tPr);
+            ev_pending = evisc_value(s2, n2, f.sm, f.neutral, uniform_load(f.mlen0, k), f.sm ? uniform_load(g.z, k) : TF(0), z0m_c, f.tPr);
         }
         bu0 = tu0; bu1 = tu1; bv0 = tv0; bv1 = tv1;
-        if (more)
-        {
-            wait_vmem();
-            __syncthreads();
-            thm = thc; thc = thp; thp = thn;
-        }
+        wait_vmem();                  // unconditional: every path back to the loop head carries a vmcnt(0) the compiler can see
+        __syncthreads();
+        if (more) { thm = thc; thc = thp; thp = thn; }
     }
     if (c_pending >= 0) f.ev[c_pending] = ev_pending;
 }
@@ -162,8 +166,18 @@ int visc_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p
     vf.grav = TF(p->grav); vf.tPr = TF(p->tPr); vf.sm = p->surface_model; vf.neutral = p->neutral; vf.ex = ex;
     const int kc = (j0 >= 0 && (j1 - j0) * 4 <= g->jmax) ? 16 : MHH_VISC_KC;      // few rows: short k-chunks fill the GPU
     const MarchTiling t = make_march_tiling(g, NJ, kc, j0, j1);
-    if (pb == 16) hipLaunchKernelGGL((visc_march_kernel<TF, NJ, 16>), dim3(march_blocks(t)), dim3(64, NJ), 0, st, make_grid<TF>(g), vf, t);
-    else          hipLaunchKernelGGL((visc_march_kernel<TF, NJ, 4>),  dim3(march_blocks(t)), dim3(64, NJ), 0, st, make_grid<TF>(g), vf, t);
+    const dim3 nb(march_blocks(t)), bs(64, NJ);
+    const GridDev<TF> gd = make_grid<TF>(g);
+    if (vf.N2)
+    {
+        if (pb == 16) hipLaunchKernelGGL((visc_march_kernel<TF, NJ, 16, true>), nb, bs, 0, st, gd, vf, t);
+        else          hipLaunchKernelGGL((visc_march_kernel<TF, NJ, 4, true>),  nb, bs, 0, st, gd, vf, t);
+    }
+    else
+    {
+        if (pb == 16) hipLaunchKernelGGL((visc_march_kernel<TF, NJ, 16, false>), nb, bs, 0, st, gd, vf, t);
+        else          hipLaunchKernelGGL((visc_march_kernel<TF, NJ, 4, false>),  nb, bs, 0, st, gd, vf, t);
+    }
     MHH_LAUNCH_CHECK();
     return MHH_OK;
 }

@@ -4,15 +4,16 @@
 #include <cstring>
 namespace mhh
 {
-inline void lds_dma16(const void* gsrc, void* lds_wave_base)
+template<bool RAW = false> inline void lds_dma16(const void* gsrc, void* lds_wave_base)
 {
     const unsigned lane = (threadIdx.x + threadIdx.y*blockDim.x + threadIdx.z*blockDim.x*blockDim.y) & 63u;
     std::memcpy(static_cast<char*>(lds_wave_base) + lane*16, gsrc, 16);
 }
-inline void lds_dma4(const void* gsrc, void* lds_wave_base)
+template<bool RAW = false> inline void lds_dma4(const void* gsrc, void* lds_wave_base)
 {
     const unsigned lane = (threadIdx.x + threadIdx.y*blockDim.x + threadIdx.z*blockDim.x*blockDim.y) & 63u;
     std::memcpy(static_cast<char*>(lds_wave_base) + lane*4, gsrc, 4);
 }
 inline void wait_vmem() {}
+template<class T> inline T uniform_load(const T* table, int idx) { return table[idx]; }
 }
