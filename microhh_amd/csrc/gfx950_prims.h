@@ -59,6 +59,21 @@ template<bool RAW> __device__ __forceinline__ void lds_dma4(const void* gsrc, vo
                      : "=&s"(m0_saved) : "v"(gsrc), "s"(lds_address(lds_wave_base)) : "memory");
     }
 }
+// The raw form with the address split the way the hardware takes it: a wave-uniform 64-bit base in scalar registers plus a
+// per-lane 32-bit byte offset (which for a tile copy is the same on every level: computed once), and the wave's LDS
+// address as a scalar -- no vector ALU work per piece at all.
+#define MHH_RAW_DMA 1
+__device__ __forceinline__ unsigned uniform_u32(unsigned wave_uniform_value) { return __builtin_amdgcn_readfirstlane(wave_uniform_value); }
+template<int PB> __device__ __forceinline__ void lds_dma_sv(const void* uniform_base, unsigned lane_byte_offset, unsigned lds_wave_address)
+{
+    unsigned m0_saved;
+    if constexpr (PB == 16)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(m0_saved) : "v"(lane_byte_offset), "s"(uniform_base), "s"(lds_wave_address) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(m0_saved) : "v"(lane_byte_offset), "s"(uniform_base), "s"(lds_wave_address) : "memory");
+}
 // Load of a wave-uniform element of a read-only table (per-level metrics, base-state profiles) through the constant
 // address space, i.e. as an s_load on the scalar cache, tracked by lgkmcnt. A plain load of such an element inside a loop
 // that also stores is emitted as a VECTOR load (the compiler cannot prove the table is not clobbered), and its

@@ -180,22 +180,38 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
     };
     // LDS-DMA movers: PB bytes per lane straight into the ring slot; lanes outside the tile / the array sit out
     const int wave_e0 = tid & ~63;                                    // first piece index of this wave within a sweep
-    auto dma_piece = [](const uint32_t* src, uint32_t* dst) { if constexpr (PB == 16) lds_dma16<(sizeof(TF) == 8)>(src, dst); else lds_dma4<(sizeof(TF) == 8)>(src, dst); };
+    // SV: the copy as scalar base + per-lane byte offset + scalar LDS address (fp64 form, gfx950_prims.h): no vector ALU per piece
+#ifdef MHH_DMA_NO_SV
+    constexpr bool SV = false;
+#else
+    constexpr bool SV = DMA && (MHH_RAW_DMA != 0) && (sizeof(TF) == 8);
+#endif
+    const unsigned wave_lds = uniform_u32((unsigned)(wave_e0*PW*4));
+    auto dma_piece = [&](const TF* plane, int word_off, TF* lds, int n)
+    {
+        if constexpr (SV) lds_dma_sv<PB>(plane, (unsigned)word_off*4u, lds_address(lds) + (wave_lds + (unsigned)(n*NT*PW*4)));
+        else
+        {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(plane) + word_off;
+            uint32_t* dst = reinterpret_cast<uint32_t*>(lds) + (size_t)(wave_e0 + n*NT)*PW;
+            if constexpr (PB == 16) lds_dma16<(sizeof(TF) == 8)>(src, dst); else lds_dma4<(sizeof(TF) == 8)>(src, dst);
+        }
+    };
     auto dma_tile = [&](const TF* __restrict__ fld, int kp, TF* __restrict__ lds)
     {
         if (kp < 0 || kp >= g.kcells) return;                         // wave-uniform
-        const uint32_t* __restrict__ pl = reinterpret_cast<const uint32_t*>(fld + (size_t)kp*kk);
+        const TF* __restrict__ pl = fld + (size_t)kp*kk;
 #pragma unroll
         for (int n=0; n<NLD; ++n)
-            if (okt[n]) dma_piece(pl + off[n], reinterpret_cast<uint32_t*>(lds) + (size_t)(wave_e0 + n*NT)*PW);
+            if (okt[n]) dma_piece(pl, off[n], lds, n);
     };
     auto dma_etile = [&](int kp, TF* __restrict__ lds)
     {
         if (kp < 0 || kp >= g.kcells) return;
-        const uint32_t* __restrict__ pl = reinterpret_cast<const uint32_t*>(f.ev + (size_t)kp*kk);
+        const TF* __restrict__ pl = f.ev + (size_t)kp*kk;
 #pragma unroll
         for (int n=0; n<NLDE; ++n)
-            if (oke[n]) dma_piece(pl + offe[n], reinterpret_cast<uint32_t*>(lds) + (size_t)(wave_e0 + n*NT)*PW);
+            if (oke[n]) dma_piece(pl, offe[n], lds, n);
     };
     auto colval = [&](const TF* __restrict__ fld, int kp) -> TF
     {

@@ -59,10 +59,17 @@ struct TileCopy
     static constexpr int PPR = TI*EW / PW, NP = PPR*TJ, NLD = (NP + NT - 1) / NT;
     static_assert(PB == 4 || PB == 16, "piece size");
     static_assert((TI*EW) % PW == 0, "tile row must be a whole number of pieces");
-    int off[NLD]; bool ok[NLD]; int wave_e0;
+    // SV: scalar-base + lane-offset form of the raw copy (fp64 kernels, see gfx950_prims.h); -DMHH_DMA_NO_SV: the 64-bit-address form
+#ifdef MHH_DMA_NO_SV
+    static constexpr bool SV = false;
+#else
+    static constexpr bool SV = (MHH_RAW_DMA != 0) && (sizeof(TF) == 8);
+#endif
+    int off[NLD]; bool ok[NLD]; int wave_e0; unsigned wave_lds;
     __device__ __forceinline__ void init(int tid, int gi0, int gj0, int icells, int jcells)
     {
         wave_e0 = tid & ~63;
+        wave_lds = uniform_u32((unsigned)(wave_e0*PW*4));       // byte offset of this wave's lanes within a slot, as a scalar
 #pragma unroll
         for (int n=0; n<NLD; ++n)
         {
@@ -81,7 +88,8 @@ struct TileCopy
         for (int n=0; n<NLD; ++n)
             if (ok[n])
             {
-                if constexpr (PB == 16) lds_dma16<(sizeof(TF) == 8)>(pl + off[n], dst + (size_t)(wave_e0 + n*NT)*PW);
+                if constexpr (SV)       lds_dma_sv<PB>(plane, (unsigned)off[n]*4u, lds_address(lds) + (wave_lds + (unsigned)(n*NT*PW*4)));
+                else if constexpr (PB == 16) lds_dma16<(sizeof(TF) == 8)>(pl + off[n], dst + (size_t)(wave_e0 + n*NT)*PW);
                 else                    lds_dma4<(sizeof(TF) == 8)>(pl + off[n], dst + (size_t)(wave_e0 + n*NT)*PW);
             }
     }

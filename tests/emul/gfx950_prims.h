@@ -15,5 +15,9 @@ template<bool RAW = false> inline void lds_dma4(const void* gsrc, void* lds_wave
     std::memcpy(static_cast<char*>(lds_wave_base) + lane*4, gsrc, 4);
 }
 inline void wait_vmem() {}
+#define MHH_RAW_DMA 0
+inline unsigned lds_address(void*) { return 0; }
+inline unsigned uniform_u32(unsigned v) { return v; }
+template<int PB> inline void lds_dma_sv(const void*, unsigned, unsigned) {}
 template<class T> inline T uniform_load(const T* table, int idx) { return table[idx]; }
 }
