@@ -559,6 +559,14 @@ __global__ void __launch_bounds__(128) hdma_solve_kernel(TF* __restrict__ p, con
 template<bool POW2, class TF>
 __device__ __forceinline__ TF fft_norm(TF v, int itot, int jtot, TF ri, TF rj) { return POW2 ? (v * rj) * ri : v / jtot / itot; }
 static inline bool is_pow2(int n) { return n > 0 && (n & (n-1)) == 0; }
+// Block b of a launch runs on XCD b % 8 (round-robin dispatch). chunk_of_block deals the chunks of a plane so that every
+// XCD owns ONE contiguous run of them: the row j-1 a cell reads then sits in the L2 of the XCD that read it as row j
+// (unpack+output at 512^3: HBM fetch 6.8 -> see profiles, r1j).
+__device__ __forceinline__ int chunk_of_block(int b, int nb)
+{
+    const int per = nb >> 3, rem = nb & 7, xcd = b & 7, idx = b >> 3;
+    return xcd*per + (xcd < rem ? xcd : rem) + idx;
+}
 
 // Threads run over the flattened (i, j) plane of the ghosted layout (rows of icells are contiguous, so a wave still stores
 // one contiguous run): no thread of a block is idle whatever icells is.
@@ -566,7 +574,7 @@ template<bool POW2, class TF>
 __global__ void __launch_bounds__(256) unpack_kernel(TF* __restrict__ p, const TF* __restrict__ packed, int order,
                                                      int itot, int jtot, int kmax, int igc, int jgc, int kgc, int icells, int jcells)
 {
-    const int ijc = blockIdx.x*256 + threadIdx.x;
+    const int ijc = chunk_of_block(blockIdx.x, gridDim.x)*256 + threadIdx.x;
     const int kz = blockIdx.z;                 // 0 .. kmax-1 + nghost rows
     if (ijc >= icells*jcells) return;
     const int j = ijc / icells, i = ijc - j*icells;
@@ -623,7 +631,7 @@ __global__ void __launch_bounds__(256) unpack_out2_kernel(TF* __restrict__ p, co
                                                           TF* __restrict__ ut, TF* __restrict__ vt, TF* __restrict__ wt, const TF* __restrict__ dzhi,
                                                           TF dxi, TF dyi, int itot, int jtot, int kmax, int igc, int jgc, int kgc, int icells, int jcells)
 {
-    const int ijc = blockIdx.x*256 + threadIdx.x;
+    const int ijc = chunk_of_block(blockIdx.x, gridDim.x)*256 + threadIdx.x;
     const int kz = blockIdx.z;                 // 0 .. kmax-1, kmax = the bottom ghost row
     if (ijc >= icells*jcells) return;
     const int j = ijc / icells, i = ijc - j*icells;
