@@ -213,9 +213,9 @@ def main():
     }
     if args.workload == "drycblles512" and world == 1 and not args.unfused:
         # HBM bytes per launch of this kernel on this workload from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and
-        # WRITE_SIZE in separate runs, FETCH_SIZE doubled for gfx950): profiles/r1e_kernels_pmc.md
-        out["roofline"]["traffic"] = (7.295e6 * 2 + 4.265e6) * 1024
-        out["roofline"]["traffic_source"] = "profiles/r1e_kernels_pmc.md"
+        # WRITE_SIZE in separate runs, FETCH_SIZE doubled for gfx950): profiles/r1j_kernels_pmc.md
+        out["roofline"]["traffic"] = (7.4575e6 * 2 + 4.3092e6) * 1024
+        out["roofline"]["traffic_source"] = "profiles/r1j_kernels_pmc.md"
     if not on_gpu:
         out["data"] = "synthetic; CPU REHEARSAL of the script (emulated kernels, gloo): not a measurement"
     if on_gpu and args.share_gpu:
