@@ -164,6 +164,12 @@ int mhh_smag2_strain2(const mhh_grid* g, int surface_model, void* strain2,
  * (mhh_smag2_mlen0_host; `g` then carries HOST metric pointers) and uploaded by the caller -- what
  * Diff_smag2::prepare_device does in the reference's GPU path (src/diff_smag2.cu:521-542).               */
 int mhh_smag2_mlen0_host(const mhh_grid* g_host, double cs, void* mlen0_host_out);
+/* mlen2[kcells]: the squared mixing length of calc_evisc / calc_evisc_neutral (src/diff_smag2.cxx:273-276,325-328:
+ * wall-damped with kappa*(z+z0m) under a surface model, mlen0^2 otherwise) for a HORIZONTALLY UNIFORM roughness length
+ * z0m, evaluated on the host with the same IEEE operations as the kernels (same bits). Optional: passed as
+ * mhh_diff_params::mlen2 it replaces three divisions and a square root per cell of exec_viscosity by a table look-up.
+ * `g_host` carries HOST metric pointers (z); valid while z0m stays uniform and unchanged. */
+int mhh_smag2_mlen2_host(const mhh_grid* g_host, int surface_model, int neutral, const void* mlen0_host, double z0m, void* mlen2_host_out);
 int mhh_smag2_evisc(const mhh_grid* g, int surface_model, void* evisc, const void* N2,
                     const void* bgradbot, const void* z0m, const void* mlen0, double tPr, void* stream); /* :254-367 incl. cyclic fill */
 int mhh_smag2_evisc_neutral(const mhh_grid* g, int surface_model, void* evisc,
@@ -207,6 +213,7 @@ typedef struct mhh_diff_params
      * the same bits; the diffusion kernels read evisc one row beyond the slab only. Needs jgc >= 2 and
      * the 2-D surface inputs valid on those rows.                                                      */
     int    evisc_ghost_rows;
+    const void* mlen2;       /* [kcells] optional device table from mhh_smag2_mlen2_host (uniform z0m), or NULL */
 } mhh_diff_params;
 int mhh_diff_exec_viscosity(const mhh_grid* g, int scheme, const mhh_fields* f, const mhh_diff_params* p, void* stream);
 /* exec_viscosity over the rows [j0, j1) of [jstart-1, jend+1) only (the wall mirror and the east-west wrap still cover

@@ -30,7 +30,7 @@ class MhhFields(C.Structure):
 class MhhDiffParams(C.Structure):
     _fields_ = [("cs", cd), ("tPr", cd), ("surface_model", ci), ("neutral", ci), ("N2", vp),
                 ("th_for_N2", ci), ("thref", vp), ("grav", cd), ("mlen0", vp),
-                ("buoyancy", ci), ("threfh", vp), ("evisc_ghost_rows", ci)]
+                ("buoyancy", ci), ("threfh", vp), ("evisc_ghost_rows", ci), ("mlen2", vp)]
 
 
 FP = C.POINTER(MhhFields)
@@ -60,6 +60,7 @@ SIGNATURES = {
     "mhh_diff_w": (ci, [GP, ci, vp, vp, cd, vp]),
     "mhh_smag2_strain2": (ci, [GP, ci, vp, vp, vp, vp, vp, vp, vp]),
     "mhh_smag2_mlen0_host": (ci, [GP, cd, vp]),
+    "mhh_smag2_mlen2_host": (ci, [GP, ci, ci, vp, cd, vp]),
     "mhh_smag2_evisc": (ci, [GP, ci, vp, vp, vp, vp, vp, cd, vp]),
     "mhh_smag2_evisc_neutral": (ci, [GP, ci, vp, vp, vp, vp, vp, cd, vp]),
     "mhh_smag2_diff_u": (ci, [GP, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, cd, vp]),

@@ -480,17 +480,27 @@ MHH_HD TF smag_strain2(const TF* __restrict__ u, const TF* __restrict__ v, const
 // plain Smagorinsky length for resolved walls): pow(x, 2) and pow(y, 1/2) are evaluated as x*x and sqrt(y).
 MHH_HD double dsqrt2(double x) { return __builtin_sqrt(x); }
 MHH_HD float  dsqrt2(float x)  { return __builtin_sqrtf(x); }
+// the squared mixing length: depends on the level and the column's roughness length only (three divisions and a square root
+// per cell in fp64) -- for a horizontally uniform z0m it is a per-level table (mhh_smag2_mlen2_host, mhh_diff_params::mlen2)
 template<class TF>
-MHH_HD TF evisc_value(TF s2, TF n2, int sm, int neutral, TF mlen0_k, TF z_k, TF z0m_ij, TF tPr)
+MHH_HD TF evisc_mlen2(int sm, int neutral, TF mlen0_k, TF z_k, TF z0m_ij)
 {
-    TF fac;
-    if (!sm) fac = sq(mlen0_k);
-    else if (neutral) fac = sq(TF(1.)/(TF(1.)/mlen0_k + TF(1.)/(TF(0.4)*(z_k+z0m_ij))));
-    else fac = sq(dsqrt2(TF(1.)/(TF(1.)/sq(mlen0_k) + TF(1.)/sq(TF(0.4)*(z_k+z0m_ij)))));
+    if (!sm) return sq(mlen0_k);
+    if (neutral) return sq(TF(1.)/(TF(1.)/mlen0_k + TF(1.)/(TF(0.4)*(z_k+z0m_ij))));
+    return sq(dsqrt2(TF(1.)/(TF(1.)/sq(mlen0_k) + TF(1.)/sq(TF(0.4)*(z_k+z0m_ij)))));
+}
+template<class TF>
+MHH_HD TF evisc_from_mlen2(TF fac, TF s2, TF n2, int neutral, TF tPr)
+{
     if (neutral) return fac * dsqrt2(s2);
     TF rit = n2 / s2 / tPr;
     rit = tmin(rit, TF(1.-1.e-9));
     return fac * dsqrt2(s2) * dsqrt2(TF(1.)-rit);
+}
+template<class TF>
+MHH_HD TF evisc_value(TF s2, TF n2, int sm, int neutral, TF mlen0_k, TF z_k, TF z0m_ij, TF tPr)
+{
+    return evisc_from_mlen2(evisc_mlen2(sm, neutral, mlen0_k, z_k, z0m_ij), s2, n2, neutral, tPr);
 }
 
 // diff_u / diff_v (:369-571). fb/ft: this level takes the surface flux at the bottom / top instead of the resolved gradient.

@@ -116,7 +116,7 @@ struct ViscosityOp
     const TF* __restrict__ u; const TF* __restrict__ v; const TF* __restrict__ w;
     const TF* __restrict__ dudz; const TF* __restrict__ dvdz; const TF* __restrict__ dbdz; const TF* __restrict__ z0m;
     const TF* __restrict__ N2; const TF* __restrict__ th; const TF* __restrict__ thref; TF grav;
-    const TF* __restrict__ mlen0; TF tPr;
+    const TF* __restrict__ mlen0; TF tPr; const TF* __restrict__ mlen2;
     __device__ void operator()(int i, int j, int k, int c) const
     {
         const int ij = i + j*g.icells;
@@ -130,7 +130,8 @@ struct ViscosityOp
             else if (N2) n2 = N2[c];
             else n2 = grav/thref[k]*TF(0.5)*(th[c+g.ijcells] - th[c-g.ijcells])*g.dzi[k];
         }
-        ev[c] = evisc_value(s2, n2, sm, neutral, mlen0[k], sm ? g.z[k] : TF(0), sm ? z0m[ij] : TF(0), tPr);
+        const TF fac = mlen2 ? mlen2[k] : evisc_mlen2(sm, neutral, mlen0[k], sm ? g.z[k] : TF(0), sm ? z0m[ij] : TF(0));
+        ev[c] = evisc_from_mlen2(fac, s2, n2, neutral, tPr);
     }
 };
 template<class TF>
@@ -169,7 +170,7 @@ static int viscosity_rows(const mhh_grid* g, const mhh_fields* f, const mhh_diff
     // the k-marching LDS kernel (k_visc.hip), or one thread per cell where it declines
     const int marched = whole ? mhh_visc_march(g, f, p, th, stream) : mhh_visc_march_rows(g, f, p, th, ja, jb, stream);
 #define CALL(TF) [&]{ ViscosityOp<TF> op{make_grid<TF>(g), p->surface_model, p->neutral, mp<TF>(f->evisc), cp<TF>(f->u), cp<TF>(f->v), cp<TF>(f->w), \
-                          cp<TF>(f->dudz), cp<TF>(f->dvdz), cp<TF>(f->dbdz), cp<TF>(f->z0m), cp<TF>(p->N2), cp<TF>(th), cp<TF>(p->thref), TF(p->grav), cp<TF>(p->mlen0), TF(p->tPr)}; \
+                          cp<TF>(f->dudz), cp<TF>(f->dvdz), cp<TF>(f->dbdz), cp<TF>(f->z0m), cp<TF>(p->N2), cp<TF>(th), cp<TF>(p->thref), TF(p->grav), cp<TF>(p->mlen0), TF(p->tPr), cp<TF>(p->mlen2)}; \
                       if (marched < 0) return -marched; \
                       if (!marched) { if (whole) { if (int e = launch_interior(st, op.g, g->kstart, g->kend, op)) return e; } \
                                       else if (int e = launch_cells(st, op, g->istart, g->iend, ja, jb, g->kstart, g->kend, g->icells, g->ijcells)) return e; } \

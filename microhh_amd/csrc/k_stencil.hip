@@ -454,6 +454,19 @@ MHH_API int mhh_smag2_mlen0_host(const mhh_grid* g, double cs, void* out)
     return MHH_OK;
 }
 
+// host helper: the squared mixing length per level for a horizontally uniform z0m -- evisc_mlen2 (cell_ops.h), the very
+// function the kernels evaluate per cell, on IEEE-correct operations (same bits on the host as on the device).
+MHH_API int mhh_smag2_mlen2_host(const mhh_grid* g, int sm, int neutral, const void* mlen0, double z0m, void* out)
+{
+    if (int e = check_grid(g)) return e;
+    MHH_REQUIRE(mlen0 && out && (!sm || g->z), "null pointer");
+    if (g->dtype == MHH_F64)
+        for (int k=0; k<g->kcells; ++k) mp<double>(out)[k] = evisc_mlen2<double>(sm, neutral, cp<double>(mlen0)[k], sm ? cp<double>(g->z)[k] : 0., z0m);
+    else
+        for (int k=0; k<g->kcells; ++k) mp<float>(out)[k] = evisc_mlen2<float>(sm, neutral, cp<float>(mlen0)[k], sm ? cp<float>(g->z)[k] : 0.f, (float)z0m);
+    return MHH_OK;
+}
+
 template<class TF>
 static int evisc_finish(const mhh_grid* g, const GridDev<TF>& gd, int sm, void* ev, hipStream_t st)
 {

@@ -22,7 +22,7 @@ template<class TF> struct ViscFields
 {
     const TF* __restrict__ u; const TF* __restrict__ v; const TF* __restrict__ w; TF* __restrict__ ev;
     const TF* __restrict__ dudz; const TF* __restrict__ dvdz; const TF* __restrict__ dbdz; const TF* __restrict__ z0m;
-    const TF* __restrict__ N2; const TF* __restrict__ th; const TF* __restrict__ thref; const TF* __restrict__ mlen0;
+    const TF* __restrict__ N2; const TF* __restrict__ th; const TF* __restrict__ thref; const TF* __restrict__ mlen0; const TF* __restrict__ mlen2;
     TF grav, tPr; int sm, neutral, ex;
 };
 
@@ -145,7 +145,9 @@ __global__ void __launch_bounds__(64*NJ, MHH_VISC_OCC) visc_march_kernel(const G
                 else n2 = f.grav/uniform_load(f.thref, k)*TF(0.5)*(thp - thm)*uniform_load(g.dzi, k);
             }
             c_pending = c;
-            ev_pending = evisc_value(s2, n2, f.sm, f.neutral, uniform_load(f.mlen0, k), f.sm ? uniform_load(g.z, k) : TF(0), z0m_c, f.tPr);
+            const TF fac = f.mlen2 ? uniform_load(f.mlen2, k)            // uniform z0m: per-level table, same bits
+                                   : evisc_mlen2(f.sm, f.neutral, uniform_load(f.mlen0, k), f.sm ? uniform_load(g.z, k) : TF(0), z0m_c);
+            ev_pending = evisc_from_mlen2(fac, s2, n2, f.neutral, f.tPr);
         }
         bu0 = tu0; bu1 = tu1; bv0 = tv0; bv1 = tv1;
         wait_vmem();                  // unconditional: every path back to the loop head carries a vmcnt(0) the compiler can see
@@ -162,7 +164,7 @@ int visc_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p
     ViscFields<TF> vf;
     vf.u = cp<TF>(f->u); vf.v = cp<TF>(f->v); vf.w = cp<TF>(f->w); vf.ev = mp<TF>(f->evisc);
     vf.dudz = cp<TF>(f->dudz); vf.dvdz = cp<TF>(f->dvdz); vf.dbdz = cp<TF>(f->dbdz); vf.z0m = cp<TF>(f->z0m);
-    vf.N2 = cp<TF>(p->N2); vf.th = cp<TF>(th); vf.thref = cp<TF>(p->thref); vf.mlen0 = cp<TF>(p->mlen0);
+    vf.N2 = cp<TF>(p->N2); vf.th = cp<TF>(th); vf.thref = cp<TF>(p->thref); vf.mlen0 = cp<TF>(p->mlen0); vf.mlen2 = cp<TF>(p->mlen2);
     vf.grav = TF(p->grav); vf.tPr = TF(p->tPr); vf.sm = p->surface_model; vf.neutral = p->neutral; vf.ex = ex;
     const int kc = (j0 >= 0 && (j1 - j0) * 4 <= g->jmax) ? 16 : MHH_VISC_KC;      // few rows: short k-chunks fill the GPU
     const MarchTiling t = make_march_tiling(g, NJ, kc, j0, j1);

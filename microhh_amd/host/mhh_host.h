@@ -279,7 +279,7 @@ class Diff
 {
     public:
         Diff(Grid<TF>& gridin, Fields<TF>& fieldsin, Boundary<TF>& boundaryin, int schemein, double dnmaxin = 0.4, TF csin = 0.23, TF tPrin = 1./3.) :
-            tPr(tPrin), grid(gridin), fields(fieldsin), boundary(boundaryin), scheme(schemein), dnmax(dnmaxin), cs(csin), dnmul(0), mlen0_g(nullptr), work(nullptr) {}
+            tPr(tPrin), grid(gridin), fields(fieldsin), boundary(boundaryin), scheme(schemein), dnmax(dnmaxin), cs(csin), dnmul(0), mlen0_g(nullptr), work(nullptr), mlen2_g(nullptr), mlen2_neutral(false) {}
         virtual ~Diff() {}
         static std::shared_ptr<Diff> factory(Grid<TF>& g, Fields<TF>& f, Boundary<TF>& b, const std::string& swdiff, double dnmax = 0.4, TF cs = 0.23, TF tPr = 1./3.)
         {
@@ -313,7 +313,23 @@ class Diff
             upload(mlen0_device, ml.data(), ml.size()*sizeof(TF));
             mlen0_g = mlen0_device;
         }
-        void clear_device() { mlen0_g = nullptr; }
+        // Optional second table for a horizontally UNIFORM roughness length (swconstantz0-like set-ups): the squared mixing
+        // length of calc_evisc per level (mhh_smag2_mlen2_host, same bits as the per-cell evaluation). Call after
+        // prepare_device with the thermo switch known; mlen2_device = caller-owned [kcells] device buffer. Drop it
+        // (clear_uniform_z0m) as soon as z0m may vary in the horizontal.
+        template<class Upload> void set_uniform_z0m(TF z0m, bool neutral, TF* mlen2_device, Upload upload)
+        {
+            if (scheme != MHH_DIFF_SMAG2) return;
+            auto& gd = grid.get_grid_data();
+            std::vector<TF> ml(gd.kcells), m2(gd.kcells);
+            mhh_grid gh = grid.abi(true);
+            mhh_check(mhh_smag2_mlen0_host(&gh, cs, ml.data()));
+            mhh_check(mhh_smag2_mlen2_host(&gh, boundary.get_switch() != "default", neutral ? 1 : 0, ml.data(), (double)z0m, m2.data()));
+            upload(mlen2_device, m2.data(), m2.size()*sizeof(TF));
+            mlen2_g = mlen2_device; mlen2_neutral = neutral;
+        }
+        void clear_uniform_z0m() { mlen2_g = nullptr; }
+        void clear_device() { mlen0_g = nullptr; mlen2_g = nullptr; }
         void exec_viscosity(Thermo<TF>& thermo, void* stream = nullptr)
         {
             if (scheme != MHH_DIFF_SMAG2) return;
@@ -372,6 +388,7 @@ class Diff
             mhh_diff_params p{};
             p.cs = cs; p.tPr = tPr; p.surface_model = (boundary.get_switch() != "default"); p.mlen0 = mlen0_g;
             p.neutral = thermo ? (thermo->get_switch() == "0") : 0;
+            if (mlen2_g && mlen2_neutral == (p.neutral != 0)) p.mlen2 = mlen2_g;
             p.th_for_N2 = -1;
             if (thermo && !p.neutral)
             {
@@ -382,7 +399,7 @@ class Diff
         }
         TF tPr;
     protected:
-        Grid<TF>& grid; Fields<TF>& fields; Boundary<TF>& boundary; int scheme; double dnmax; TF cs; double dnmul; TF* mlen0_g; void* work;
+        Grid<TF>& grid; Fields<TF>& fields; Boundary<TF>& boundary; int scheme; double dnmax; TF cs; double dnmul; TF* mlen0_g; void* work; TF* mlen2_g; bool mlen2_neutral;
 };
 
 // ---- Pres (include/pres.h:39-85) ---------------------------------------------------------------------------------

@@ -139,6 +139,14 @@ class HotPath:
             self._ok(self.lib.mhh_smag2_mlen0_host(g.host_struct(), p.cs, ml.ctypes.data))
             self.mlen0 = torch.from_numpy(ml).to(self.device)
             p.mlen0 = self.mlen0.data_ptr()
+            # Diff_smag2::prepare_device, continued: a horizontally uniform roughness length makes the squared mixing length a
+            # per-level table (same bits as the per-cell evaluation; three divisions and a square root per cell less)
+            z0 = self.surf["z0m"]
+            if bool((z0 == z0.flatten()[0]).all()):
+                m2 = np.zeros(g.kcells, dtype=g.np_dtype)
+                self._ok(self.lib.mhh_smag2_mlen2_host(g.host_struct(), p.surface_model, p.neutral, ml.ctypes.data, float(z0.flatten()[0]), m2.ctypes.data))
+                self.mlen2 = torch.from_numpy(m2).to(self.device)
+                p.mlen2 = self.mlen2.data_ptr()
         self.fields = self._fields()
         # Pres::init / set_values / prepare_device
         self.plan = capi.PLAN()

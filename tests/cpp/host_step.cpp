@@ -51,7 +51,8 @@ int main(int argc, char** argv)
         fields.mp["v"]->flux_bot_g = up(rd(in, n2)); fields.mp["v"]->flux_top_g = up(rd(in, n2));
         fields.sp["th"]->flux_bot_g = up(rd(in, n2)); fields.sp["th"]->flux_top_g = up(rd(in, n2));
         Boundary<TF> boundary; boundary.swboundary = sm ? "surface" : "default";
-        boundary.dudz_g = up(rd(in, n2)); boundary.dvdz_g = up(rd(in, n2)); boundary.dbdz_g = up(rd(in, n2)); boundary.z0m_g = up(rd(in, n2));
+        boundary.dudz_g = up(rd(in, n2)); boundary.dvdz_g = up(rd(in, n2)); boundary.dbdz_g = up(rd(in, n2));
+        const std::vector<TF> z0m_h = rd(in, n2); boundary.z0m_g = up(z0m_h);
         Thermo<TF> thermo; thermo.swthermo = "dry"; thermo.thref_g = up(rd(in, nk)); thermo.grav = 9.81;
         if (buoy) thermo.threfh_g = up(rd(in, nk));
         std::fclose(in);
@@ -67,6 +68,14 @@ int main(int argc, char** argv)
         advec->set_reduce_workspace(work); diff->set_reduce_workspace(work); pres->set_reduce_workspace(work);
         diff->prepare_device(boundary, mlen0, [](void* d, const void* s, size_t n) { HIPCHK(hipMemcpy(d, s, n, hipMemcpyHostToDevice)); });
         pres->prepare_device();
+        // a horizontally uniform roughness length: the per-level mixing-length table (same bits as the per-cell evaluation)
+        TF* mlen2 = nullptr;
+        bool z0_uniform = true; for (TF v : z0m_h) z0_uniform = z0_uniform && (v == z0m_h[0]);
+        if (z0_uniform)
+        {
+            HIPCHK(hipMalloc((void**)&mlen2, nk*sizeof(TF)));
+            diff->set_uniform_z0m(z0m_h[0], false, mlen2, [](void* d, const void* s, size_t n) { HIPCHK(hipMemcpy(d, s, n, hipMemcpyHostToDevice)); });
+        }
 
         // ---- the slice of Model::exec this package accelerates (src/model.cxx:346-411) ----
         for (auto& it : fields.mp) boundary_cyclic.exec_g(it.second->fld_g);

@@ -551,6 +551,42 @@ def test_exec_viscosity_marching_form_equals_cell_form(be, sm, neutral, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("sm,neutral", [(1, 0), (0, 0), (1, 1)])
+def test_exec_viscosity_with_the_mixing_length_table_equals_per_cell_evaluation(be, sm, neutral, dtype):
+    """mhh_diff_params::mlen2 (mhh_smag2_mlen2_host: the squared mixing length per level for a horizontally uniform z0m,
+    evaluated on the HOST) against the per-cell evaluation on the device: the same bits in both kernel forms -- IEEE
+    division and square root round alike on either side."""
+    for shape in [(70, 10, 12), (18, 9, 8)]:
+        g = cm.grid_2nd(*shape, gc=(3, 3, 1), dtype=dtype)
+        c = cm.Case(g, periodic=True)
+        assert (c.z0m == c.z0m.flat[0]).all()
+        thref = np.full(g.kcells, 300., dtype=dtype)
+        out = {}
+        for impl in ("march", "cell"):
+            for table in (False, True):
+                d = B.DevCase(be, c); f = d.fields()
+                p = capi.MhhDiffParams(); p.cs = 0.23; p.tPr = 1./3.; p.surface_model = sm; p.neutral = neutral
+                p.N2 = None; p.th_for_N2 = 0; dthref = be.arr(thref); p.thref = be.ptr(dthref).value; p.grav = 9.81
+                ml_h = np.zeros(g.kcells, dtype=dtype)
+                B.ok(be, be.lib.mhh_smag2_mlen0_host(g.host_struct(), 0.23, ptr(ml_h)))
+                ml = be.arr(ml_h); p.mlen0 = be.ptr(ml).value
+                if table:
+                    m2_h = np.zeros(g.kcells, dtype=dtype)
+                    B.ok(be, be.lib.mhh_smag2_mlen2_host(g.host_struct(), sm, neutral, ptr(ml_h), float(c.z0m.flat[0]), ptr(m2_h)))
+                    assert (m2_h[g.kstart:g.kend] > 0).all()
+                    m2 = be.arr(m2_h); p.mlen2 = be.ptr(m2).value
+                os.environ["MHH_VISC_IMPL"] = impl
+                try:
+                    B.ok(be, be.lib.mhh_diff_exec_viscosity(d.G, cm.DIFF_SMAG2, C.byref(f), C.byref(p), be.stream))
+                finally:
+                    del os.environ["MHH_VISC_IMPL"]
+                out[impl, table] = be.host(d.evisc)
+        for impl in ("march", "cell"):
+            assert same(out[impl, True], out[impl, False]), (impl, shape, cm.ulp_diff(out[impl, True], out[impl, False]))
+        assert same(out["march", True], out["cell", True])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("order", [2, 4])
 def test_pres(be, order, dtype):
     O = cm.oracle()
