@@ -656,6 +656,50 @@ __global__ void __launch_bounds__(256) unpack_out2_kernel(TF* __restrict__ p, co
     }
 }
 
+// The same for pres_4 (src/pres_4.cxx:481-571): the four mirrored ghost levels of p are written like unpack_kernel does, and an
+// interior cell gathers the 4-point gradient stencils in x, y and z straight from the packed solution -- wrapped in the
+// horizontal, mirrored across the walls in the vertical (p[kstart-1] = p[kstart], p[kstart-2] = p[kstart+1], likewise on top).
+template<bool POW2, class TF>
+__global__ void __launch_bounds__(256) unpack_out4_kernel(TF* __restrict__ p, const TF* __restrict__ packed,
+                                                          TF* __restrict__ ut, TF* __restrict__ vt, TF* __restrict__ wt, const TF* __restrict__ dzhi4,
+                                                          TF dxi, TF dyi, int dim3, int itot, int jtot, int kmax, int igc, int jgc, int kgc, int icells, int jcells)
+{
+    const int ijc = chunk_of_block(blockIdx.x, gridDim.x)*256 + threadIdx.x;
+    const int kz = blockIdx.z;                 // 0 .. kmax-1, then the four ghost levels
+    if (ijc >= icells*jcells) return;
+    const int j = ijc / icells, i = ijc - j*icells;
+    const TF ri = TF(1)/TF(itot), rj = TF(1)/TF(jtot);
+    int kd, ks;
+    if (kz < kmax) { kd = kz + kgc; ks = kz; }
+    else
+    {
+        const int gidx = kz - kmax;
+        if (gidx == 0)      { kd = kgc - 1;      ks = 0; }
+        else if (gidx == 1) { kd = kgc - 2;      ks = 1; }
+        else if (gidx == 2) { kd = kgc + kmax;   ks = kmax-1; }
+        else                { kd = kgc + kmax+1; ks = kmax-2; }
+    }
+    int is = (i - igc) % itot; if (is < 0) is += itot;
+    int js = (j - jgc) % jtot; if (js < 0) js += jtot;
+    const size_t ij = (size_t)itot*jtot;
+    auto P = [&](int ii, int jw, int kk) -> TF                 // normalised solution at wrapped (ii, jw), mirrored level kk
+    {
+        int iw = ii % itot; if (iw < 0) iw += itot;
+        int jv = jw % jtot; if (jv < 0) jv += jtot;
+        const int kv = (kk < 0) ? -kk-1 : (kk >= kmax ? 2*kmax-1-kk : kk);
+        return fft_norm<POW2>(packed[(size_t)iw + (size_t)jv*itot + (size_t)kv*ij], itot, jtot, ri, rj);
+    };
+    const TF pc = P(is, js, ks);
+    const size_t c = (size_t)ijc + (size_t)kd*icells*jcells;
+    p[c] = pc;
+    if (kz < kmax && i >= igc && i < igc + itot && j >= jgc && j < jgc + jtot)
+    {
+        ut[c] -= cg4(P(is-2, js, ks), P(is-1, js, ks), pc, P(is+1, js, ks)) * dxi;
+        if (dim3) vt[c] -= cg4(P(is, js-2, ks), P(is, js-1, ks), pc, P(is, js+1, ks)) * dyi;
+        if (ks > 0) wt[c] -= cg4(P(is, js, ks-2), P(is, js, ks-1), pc, P(is, js, ks+1)) * dzhi4[kd];
+    }
+}
+
 // forward transform, column solves, inverse transform: packed rhs -> packed (un-normalised) solution
 static int pres_spectral(mhh_pres_plan* P, const mhh_grid* g, void* p_packed, hipStream_t st)
 {
@@ -852,6 +896,25 @@ MHH_API int mhh_pres_exec(mhh_pres_plan* P, const mhh_grid* g, const mhh_fields*
                                    gd.dxi_t, gd.dyi_t, g->itot, g->jtot, g->kmax, g->igc, g->jgc, g->kgc, g->icells, g->jcells); \
                 else hipLaunchKernelGGL((unpack_out2_kernel<false, TF>), ug, dim3(256), 0, st, mp<TF>(f->p), cp<TF>(P->packed), mp<TF>(f->ut), mp<TF>(f->vt), mp<TF>(f->wt), gd.dzhi, \
                                    gd.dxi_t, gd.dyi_t, g->itot, g->jtot, g->kmax, g->igc, g->jgc, g->kgc, g->icells, g->jcells); return MHH_OK; }()
+            if (int e = MHH_DISPATCH(g, CALL)) return e;
+#undef CALL
+            MHH_LAUNCH_CHECK();
+            return MHH_OK;
+        }
+        if (P->order == 4 && !(uo && !strcmp(uo, "0")))
+        {
+            if (int e = check_grid(g)) return e;
+            MHH_REQUIRE(f && f->p && f->ut && f->vt && f->wt, "null field");
+            MHH_REQUIRE(P->dtype == g->dtype && P->itot == g->itot && P->jtot == g->jtot && P->ktot == g->ktot, "plan/grid mismatch");
+            hipStream_t st = as_stream(stream);
+            if (int e = pres_spectral(P, g, P->packed, st)) return e;
+            dim3 ug((g->icells*g->jcells + 255)/256, 1, g->kmax + 4);
+            const bool pow2 = is_pow2(g->itot) && is_pow2(g->jtot);
+#define CALL(TF) [&]{ const GridDev<TF> gd = make_grid<TF>(g); \
+                if (pow2) hipLaunchKernelGGL((unpack_out4_kernel<true, TF>), ug, dim3(256), 0, st, mp<TF>(f->p), cp<TF>(P->packed), mp<TF>(f->ut), mp<TF>(f->vt), mp<TF>(f->wt), gd.dzhi4, \
+                                   gd.dxi_d, gd.dyi_d, (int)gd.dim3, g->itot, g->jtot, g->kmax, g->igc, g->jgc, g->kgc, g->icells, g->jcells); \
+                else hipLaunchKernelGGL((unpack_out4_kernel<false, TF>), ug, dim3(256), 0, st, mp<TF>(f->p), cp<TF>(P->packed), mp<TF>(f->ut), mp<TF>(f->vt), mp<TF>(f->wt), gd.dzhi4, \
+                                   gd.dxi_d, gd.dyi_d, (int)gd.dim3, g->itot, g->jtot, g->kmax, g->igc, g->jgc, g->kgc, g->icells, g->jcells); return MHH_OK; }()
             if (int e = MHH_DISPATCH(g, CALL)) return e;
 #undef CALL
             MHH_LAUNCH_CHECK();

@@ -390,6 +390,33 @@ def test_unpack_normalisation_is_two_divisions_bit_for_bit(be, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_pres4_exec_unpack_and_output_in_one_kernel_equals_two(be, dtype):
+    """The same for pres_4: four mirrored ghost levels of p, 4-point gradients gathered from the packed solution (wrapped in the
+    horizontal, mirrored across the walls), wt untouched at kstart, vt untouched on a 2-D grid."""
+    for g in [cm.grid_4th(16, 12, 12, dtype=dtype), cm.grid_4th(12, 1, 8, dtype=dtype), cm.grid_4th(16, 8, 8, dtype=dtype), cm.grid_4th(6, 5, 4, dtype=dtype)]:
+        c = cm.Case(g, rho="one", periodic=True)
+        for m in (1, 2):
+            c.w[g.kstart-m] = -c.w[g.kstart+m]; c.w[g.kend+m] = -c.w[g.kend-m]
+        Gh = g.host_struct(); dt = 0.7
+        out = {}
+        for form in ("one", "two"):
+            d = B.DevCase(be, c); f = d.fields()
+            plan = capi.PLAN()
+            B.ok(be, be.lib.mhh_pres_plan_create(Gh, 4, ptr(g.dz), ptr(g.dzhi), ptr(g.dzi4), ptr(g.dzhi4), ptr(c.rhoref), ptr(c.rhorefh), C.byref(plan)))
+            if form == "two":
+                os.environ["MHH_PRES_UNPACK_OUT"] = "0"
+            try:
+                B.ok(be, be.lib.mhh_pres_exec(plan, d.G, C.byref(f), dt, be.stream))
+            finally:
+                os.environ.pop("MHH_PRES_UNPACK_OUT", None)
+            out[form] = [be.host(x) for x in (d.p, d.ut, d.vt, d.wt)]
+            be.lib.mhh_pres_plan_destroy(plan)
+        for x, y, nm in zip(out["one"], out["two"], ("p", "ut", "vt", "wt")):
+            assert same(x, y), (g.shape3, nm, cm.ulp_diff(x, y))
+        assert not np.array_equal(out["one"][1], c.ut)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_pres2_exec_unpack_and_output_in_one_kernel_equals_two(be, dtype):
     """mhh_pres_exec (order 2) unpacks the solution and applies Pres_2::output in one kernel; MHH_PRES_UNPACK_OUT=0 runs
     them as the two kernels of mhh_pres_solve + mhh_pres_output. Same bits: p with every ghost cell, ut, vt, wt."""
