@@ -92,7 +92,9 @@ template<class TF> struct MarchFields
 // DMA = false: planes are staged through registers (prefetch, two barriers per level): any alignment.
 // PB = 16 : LDS-DMA in 16-byte pieces (rows 16-byte aligned); PB = 4: LDS-DMA in 4-byte pieces (global_load_lds_dword):
 //           any layout, four times the copy instructions; PB = 0: register-staged.
-template<class TF, int NJ, bool HAS_S, int PB>
+// ADV / DIF: which operator's terms are added -- both (the fused pass), or one of them: Advec::exec and Diff::exec as
+// separate calls then run the same kernel body (same bits, same order of accumulation as the fused pass in two steps).
+template<class TF, int NJ, bool HAS_S, int PB, bool ADV = true, bool DIF = true>
 __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : MHH_MARCH_OCC)) rhs25_march_kernel(const GridDev<TF> g, const MarchFields<TF> f, const MarchTiling mt)
 {
     constexpr bool DMA = (PB != 0);
@@ -110,7 +112,7 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
     __shared__ __attribute__((aligned(16))) TF V[RU][NTILE];
     __shared__ __attribute__((aligned(16))) TF W[RW][NTILE];
     __shared__ __attribute__((aligned(16))) TF S[HAS_S ? RS : 1][HAS_S ? NTILE : VEC];
-    __shared__ __attribute__((aligned(16))) TF E[RE][NETILE];
+    __shared__ __attribute__((aligned(16))) TF E[DIF ? RE : 1][DIF ? NETILE : VEC];
 
     int bx, by, kcn;
     if (!decode_march(mt, blockIdx.x, bx, by, kcn)) return;        // whole block leaves together: no barrier hazard
@@ -226,7 +228,7 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
         {
             if (p <= ks) { dma_tile(f.u, p, U[slot(p, RU)]); dma_tile(f.v, p, V[slot(p, RU)]); }
             if (p >= ks) dma_tile(f.w, p, W[slot(p, RW)]);
-            dma_etile(p, E[slot(p, RE)]);
+            if (DIF) dma_etile(p, E[slot(p, RE)]);
         }
         if (HAS_S) dma_tile(f.s, ks, S[slot(ks, RS)]);
     }
@@ -237,7 +239,7 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
         {
             if (p <= ks) { ld_tile(f.u, p, r); st_tile(U[slot(p, RU)], r); ld_tile(f.v, p, r); st_tile(V[slot(p, RU)], r); }
             if (p >= ks) { ld_tile(f.w, p, r); st_tile(W[slot(p, RW)], r); }
-            ld_etile(p, re);    st_etile(E[slot(p, RE)], re);
+            if (DIF) { ld_etile(p, re);    st_etile(E[slot(p, RE)], re); }
         }
         if (HAS_S) { ld_tile(f.s, ks, r); st_tile(S[0], r); }
     }
@@ -295,12 +297,12 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
             if constexpr (DMA)
             {
                 dma_tile(f.u, k+1, U[slot(k+1, RU)]); dma_tile(f.v, k+1, V[slot(k+1, RU)]); dma_tile(f.w, k+2, W[slot(k+2, RW)]);
-                dma_etile(k+2, E[slot(k+2, RE)]);
+                if (DIF) dma_etile(k+2, E[slot(k+2, RE)]);
                 if (HAS_S) dma_tile(f.s, k+1, S[slot(k+1, RS)]);
             }
             else
             {
-                ld_tile(f.u, k+1, pu); ld_tile(f.v, k+1, pv); ld_tile(f.w, k+2, pw); ld_etile(k+2, pe);
+                ld_tile(f.u, k+1, pu); ld_tile(f.v, k+1, pv); ld_tile(f.w, k+2, pw); if (DIF) ld_etile(k+2, pe);
                 if (HAS_S) ld_tile(f.s, k+1, ps);
             }
         }
@@ -322,7 +324,8 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
         const TF* __restrict__ vk = V[slot(k, RU)] + l;  const TF* __restrict__ vkm = V[slot(k-1, RU)] + l;
         const TF* __restrict__ wk = W[slot(k, RW)] + l;  const TF* __restrict__ wkp = W[slot(k+1, RW)] + l;
         const TF* __restrict__ sk = S[HAS_S ? slot(k, RS) : 0] + (HAS_S ? l : 0);
-        const TF* __restrict__ ek = E[slot(k, RE)] + le; const TF* __restrict__ ekm = E[slot(k-1, RE)] + le; const TF* __restrict__ ekp = E[slot(k+1, RE)] + le;
+        const TF* __restrict__ ek = E[DIF ? slot(k, RE) : 0] + (DIF ? le : 0); const TF* __restrict__ ekm = E[DIF ? slot(k-1, RE) : 0] + (DIF ? le : 0);
+        const TF* __restrict__ ekp = E[DIF ? slot(k+1, RE) : 0] + (DIF ? le : 0);
         // per-level coefficients (wave-uniform)
         // per-level coefficients: scalar loads (uniform_load), not vector loads whose wait would drain the copies in flight
         const TF rhkp = RHO1 ? TF(1) : uniform_load(f.rhorefh, k+1), rhk = RHO1 ? TF(1) : uniform_load(f.rhorefh, k), rk = RHO1 ? TF(1) : uniform_load(f.rhoref, k);
@@ -340,7 +343,7 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
         STAMP(1);
         // ---- top-face quantities of level k --------------------------------------------------------------------
         TF Tu = 0, Gu = 0, Tv = 0, Gv = 0, Tw = 0, Gw = 0, Ts = 0, Gs = 0;
-        if (otc != 0)
+        if (ADV && otc != 0)
         {
             const TF wtu = i2(wkp[-1], wkp[0]);
             const TF wtv = i2(wkp[-TI], wkp[0]);
@@ -353,14 +356,14 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
                 if (otc >= 4) Gs = R(rhkp, tabs(ww[4])) * win_upw(sw, otc);
             }
         }
-        if (wlev)
+        if (ADV && wlev)
         {
             const TF wtw = i2(ww[3], ww[4]);
             Tw = R(rk, wtw) * win_cen(ww, otw);
             if (otw >= 4) Gw = R(rk, tabs(wtw)) * win_upw(ww, otw);
         }
         TF Du = 0, Dv = 0, Dw = 0, Ds = 0;
-        if (need_dtop)
+        if (DIF && need_dtop)
         {
             const TF etu = TF(0.25)*(ek[-1] + ek[0] + ekp[-1] + ekp[0]) + visc;
             Du = R(rhkp, etu)*((uw[4]-uw[3])*dzhip + (wkp[0]-wkp[-1])*dxd);
@@ -372,7 +375,7 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
                 Ds = R(rhkp, ets)*(sw[4]-sw[3])*dzhip;
             }
         }
-        if (wlev)
+        if (DIF && wlev)
         {
             const TF etw = ek[0] + visc;
             Dw = R(rk, etw)*(ww[4]-ww[3])*dzi;
@@ -384,80 +387,107 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
         {
             const int c = col + k*kk;
             {   // u
-                const TF ue = i2(uk[0], uk[1]), uwf = i2(uk[-1], uk[0]);
-                const TF vn = i2(vk[TI-1], vk[TI]), vs = i2(vk[-1], vk[0]);
+                TF ue = 0, uwf = 0, vn = 0, vs = 0;
+                if constexpr (ADV) { ue = i2(uk[0], uk[1]); uwf = i2(uk[-1], uk[0]);
+                                     vn = i2(vk[TI-1], vk[TI]); vs = i2(vk[-1], vk[0]); }
                 TF t = TPREF ? tcu : f.ut[c];
-                t += advec25_hor(uk, 0, TI, ue, uwf, vn, vs, dxi, dyi);
-                t += vert_combine(otc, obc, Tu, cTu, Gu, cGu, rk, rk1, dzi);
-                const TF ee = ek[0] + visc, ew = ek[-1] + visc;
-                const TF en = TF(0.25)*(ek[-1   ] + ek[0  ] + ek[-1+TE] + ek[TE]) + visc;
-                const TF es = TF(0.25)*(ek[-1-TE] + ek[-TE] + ek[-1   ] + ek[0 ]) + visc;
-                const TF hor = + ( ee*(uk[1]-uk[0])*dxd - ew*(uk[0]-uk[-1])*dxd ) * TF(2.)*dxd
-                               + ( en*((uk[TI]-uk[0  ])*dyd + (vk[TI]-vk[TI-1])*dxd)
-                                 - es*((uk[0 ]-uk[-TI])*dyd + (vk[0 ]-vk[-1  ])*dxd) ) * dyd;
-                TF ver;
-                if (fb)      ver = div_rho( Du + rhk * f.ufb[ij], rk, rk1 ) * dzi;
-                else if (ft) ver = div_rho( - rhkp * f.uft[ij] - cDu, rk, rk1 ) * dzi;
-                else         ver = div_rho( Du - cDu, rk, rk1 ) * dzi;
-                t += hor + ver;
+                if constexpr (ADV)
+                {
+                    t += advec25_hor(uk, 0, TI, ue, uwf, vn, vs, dxi, dyi);
+                    t += vert_combine(otc, obc, Tu, cTu, Gu, cGu, rk, rk1, dzi);
+                }
+                if constexpr (DIF)
+                {
+                    const TF ee = ek[0] + visc, ew = ek[-1] + visc;
+                    const TF en = TF(0.25)*(ek[-1   ] + ek[0  ] + ek[-1+TE] + ek[TE]) + visc;
+                    const TF es = TF(0.25)*(ek[-1-TE] + ek[-TE] + ek[-1   ] + ek[0 ]) + visc;
+                    const TF hor = + ( ee*(uk[1]-uk[0])*dxd - ew*(uk[0]-uk[-1])*dxd ) * TF(2.)*dxd
+                                   + ( en*((uk[TI]-uk[0  ])*dyd + (vk[TI]-vk[TI-1])*dxd)
+                                     - es*((uk[0 ]-uk[-TI])*dyd + (vk[0 ]-vk[-1  ])*dxd) ) * dyd;
+                    TF ver;
+                    if (fb)      ver = div_rho( Du + rhk * f.ufb[ij], rk, rk1 ) * dzi;
+                    else if (ft) ver = div_rho( - rhkp * f.uft[ij] - cDu, rk, rk1 ) * dzi;
+                    else         ver = div_rho( Du - cDu, rk, rk1 ) * dzi;
+                    t += hor + ver;
+                }
                 dsk = k;
                 if (DSTORE == 1) dsu = t; else f.ut[c] = t;
             }
             {   // v
-                const TF ue = i2(uk[1-TI], uk[1]), uwf = i2(uk[-TI], uk[0]);
-                const TF vn = i2(vk[0], vk[TI]), vs = i2(vk[-TI], vk[0]);
+                TF ue = 0, uwf = 0, vn = 0, vs = 0;
+                if constexpr (ADV) { ue = i2(uk[1-TI], uk[1]); uwf = i2(uk[-TI], uk[0]);
+                                     vn = i2(vk[0], vk[TI]); vs = i2(vk[-TI], vk[0]); }
                 TF t = TPREF ? tcv : f.vt[c];
-                t += advec25_hor(vk, 0, TI, ue, uwf, vn, vs, dxi, dyi);
-                t += vert_combine(otc, obc, Tv, cTv, Gv, cGv, rk, rk1, dzi);
-                const TF ee = TF(0.25)*(ek[-TE  ] + ek[0 ] + ek[1-TE] + ek[1]) + visc;
-                const TF ew = TF(0.25)*(ek[-1-TE] + ek[-1] + ek[-TE ] + ek[0]) + visc;
-                const TF en = ek[0] + visc, es = ek[-TE] + visc;
-                const TF hor = + ( ee*((vk[1]-vk[0 ])*dxd + (uk[1]-uk[1-TI])*dyd)
-                                 - ew*((vk[0]-vk[-1])*dxd + (uk[0]-uk[-TI ])*dyd) ) * dxd
-                               + ( en*(vk[TI]-vk[0])*dyd - es*(vk[0]-vk[-TI])*dyd ) * TF(2.)*dyd;
-                TF ver;
-                if (fb)      ver = div_rho( Dv + rhk * f.vfb[ij], rk, rk1 ) * dzi;
-                else if (ft) ver = div_rho( - rhkp * f.vft[ij] - cDv, rk, rk1 ) * dzi;
-                else         ver = div_rho( Dv - cDv, rk, rk1 ) * dzi;
-                t += hor + ver;
+                if constexpr (ADV)
+                {
+                    t += advec25_hor(vk, 0, TI, ue, uwf, vn, vs, dxi, dyi);
+                    t += vert_combine(otc, obc, Tv, cTv, Gv, cGv, rk, rk1, dzi);
+                }
+                if constexpr (DIF)
+                {
+                    const TF ee = TF(0.25)*(ek[-TE  ] + ek[0 ] + ek[1-TE] + ek[1]) + visc;
+                    const TF ew = TF(0.25)*(ek[-1-TE] + ek[-1] + ek[-TE ] + ek[0]) + visc;
+                    const TF en = ek[0] + visc, es = ek[-TE] + visc;
+                    const TF hor = + ( ee*((vk[1]-vk[0 ])*dxd + (uk[1]-uk[1-TI])*dyd)
+                                     - ew*((vk[0]-vk[-1])*dxd + (uk[0]-uk[-TI ])*dyd) ) * dxd
+                                   + ( en*(vk[TI]-vk[0])*dyd - es*(vk[0]-vk[-TI])*dyd ) * TF(2.)*dyd;
+                    TF ver;
+                    if (fb)      ver = div_rho( Dv + rhk * f.vfb[ij], rk, rk1 ) * dzi;
+                    else if (ft) ver = div_rho( - rhkp * f.vft[ij] - cDv, rk, rk1 ) * dzi;
+                    else         ver = div_rho( Dv - cDv, rk, rk1 ) * dzi;
+                    t += hor + ver;
+                }
                 if (DSTORE == 1) dsv = t; else f.vt[c] = t;
             }
             dsw_on = (FAST || k > g.kstart);
             if (FAST || k > g.kstart)
             {   // w
-                const TF ue = i2(ukm[1], uk[1]), uwf = i2(ukm[0], uk[0]);
-                const TF vn = i2(vkm[TI], vk[TI]), vs = i2(vkm[0], vk[0]);
+                TF ue = 0, uwf = 0, vn = 0, vs = 0;
+                if constexpr (ADV) { ue = i2(ukm[1], uk[1]); uwf = i2(ukm[0], uk[0]);
+                                     vn = i2(vkm[TI], vk[TI]); vs = i2(vkm[0], vk[0]); }
                 TF t = TPREF ? tcw : f.wt[c];
                 if (HAS_S && f.threfh) { const TF th_k = uniform_load(f.threfh, k); t += f.grav/th_k * (i2(sw[2], sw[3]) - th_k); }   // src/thermo_dry.cxx:165-178
-                t += advec25_hor(wk, 0, TI, ue, uwf, vn, vs, dxi, dyi);
-                t += vert_combine(otw, obw, Tw, cTw, Gw, cGw, rhk, rhk1, dzhi);
-                const TF ee = TF(0.25)*(ekm[0  ] + ek[0  ] + ekm[1 ] + ek[1 ]) + visc;
-                const TF ew = TF(0.25)*(ekm[-1 ] + ek[-1 ] + ekm[0 ] + ek[0 ]) + visc;
-                const TF en = TF(0.25)*(ekm[0  ] + ek[0  ] + ekm[TE] + ek[TE]) + visc;
-                const TF es = TF(0.25)*(ekm[-TE] + ek[-TE] + ekm[0 ] + ek[0 ]) + visc;
-                t += + ( ee*((wk[1 ]-wk[0  ])*dxd + (uk[1 ]-ukm[1 ])*dzhi)
-                       - ew*((wk[0 ]-wk[-1 ])*dxd + (uk[0 ]-ukm[0 ])*dzhi) ) * dxd
-                     + ( en*((wk[TI]-wk[0  ])*dyd + (vk[TI]-vkm[TI])*dzhi)
-                       - es*((wk[0 ]-wk[-TI])*dyd + (vk[0 ]-vkm[0 ])*dzhi) ) * dyd
-                     + div_rho( Dw - cDw, rhk, rhk1 ) * TF(2.)*dzhi;
+                if constexpr (ADV)
+                {
+                    t += advec25_hor(wk, 0, TI, ue, uwf, vn, vs, dxi, dyi);
+                    t += vert_combine(otw, obw, Tw, cTw, Gw, cGw, rhk, rhk1, dzhi);
+                }
+                if constexpr (DIF)
+                {
+                    const TF ee = TF(0.25)*(ekm[0  ] + ek[0  ] + ekm[1 ] + ek[1 ]) + visc;
+                    const TF ew = TF(0.25)*(ekm[-1 ] + ek[-1 ] + ekm[0 ] + ek[0 ]) + visc;
+                    const TF en = TF(0.25)*(ekm[0  ] + ek[0  ] + ekm[TE] + ek[TE]) + visc;
+                    const TF es = TF(0.25)*(ekm[-TE] + ek[-TE] + ekm[0 ] + ek[0 ]) + visc;
+                    t += + ( ee*((wk[1 ]-wk[0  ])*dxd + (uk[1 ]-ukm[1 ])*dzhi)
+                           - ew*((wk[0 ]-wk[-1 ])*dxd + (uk[0 ]-ukm[0 ])*dzhi) ) * dxd
+                         + ( en*((wk[TI]-wk[0  ])*dyd + (vk[TI]-vkm[TI])*dzhi)
+                           - es*((wk[0 ]-wk[-TI])*dyd + (vk[0 ]-vkm[0 ])*dzhi) ) * dyd
+                         + div_rho( Dw - cDw, rhk, rhk1 ) * TF(2.)*dzhi;
+                }
                 if (DSTORE == 1 || DSTORE == 2) dsw = t; else f.wt[c] = t;
             }
             if (HAS_S)
             {   // scalar
                 TF t = TPREF ? tcs : f.st[c];
-                t += advec25_hor(sk, 0, TI, uk[1], uk[0], vk[TI], vk[0], dxi, dyi);
-                t += vert_combine(otc, obc, Ts, cTs, Gs, cGs, rk, rk1, dzi);
-                const TF ee = TF(0.5)*(ek[0  ]+ek[1 ])/f.tPr + f.svisc;
-                const TF ew = TF(0.5)*(ek[-1 ]+ek[0 ])/f.tPr + f.svisc;
-                const TF en = TF(0.5)*(ek[0  ]+ek[TE])/f.tPr + f.svisc;
-                const TF es = TF(0.5)*(ek[-TE]+ek[0 ])/f.tPr + f.svisc;
-                const TF hor = + ( ee*(sk[1 ]-sk[0]) - ew*(sk[0]-sk[-1 ]) ) * g.dxidxi_d
-                               + ( en*(sk[TI]-sk[0]) - es*(sk[0]-sk[-TI]) ) * g.dyidyi_d;
-                TF ver;
-                if (fb)      ver = div_rho( Ds + rhk * f.sfb[ij], rk, rk1 ) * dzi;
-                else if (ft) ver = div_rho( -rhkp * f.sft[ij] - cDs, rk, rk1 ) * dzi;
-                else         ver = div_rho( Ds - cDs, rk, rk1 ) * dzi;
-                t += hor + ver;
+                if constexpr (ADV)
+                {
+                    t += advec25_hor(sk, 0, TI, uk[1], uk[0], vk[TI], vk[0], dxi, dyi);
+                    t += vert_combine(otc, obc, Ts, cTs, Gs, cGs, rk, rk1, dzi);
+                }
+                if constexpr (DIF)
+                {
+                    const TF ee = TF(0.5)*(ek[0  ]+ek[1 ])/f.tPr + f.svisc;
+                    const TF ew = TF(0.5)*(ek[-1 ]+ek[0 ])/f.tPr + f.svisc;
+                    const TF en = TF(0.5)*(ek[0  ]+ek[TE])/f.tPr + f.svisc;
+                    const TF es = TF(0.5)*(ek[-TE]+ek[0 ])/f.tPr + f.svisc;
+                    const TF hor = + ( ee*(sk[1 ]-sk[0]) - ew*(sk[0]-sk[-1 ]) ) * g.dxidxi_d
+                                   + ( en*(sk[TI]-sk[0]) - es*(sk[0]-sk[-TI]) ) * g.dyidyi_d;
+                    TF ver;
+                    if (fb)      ver = div_rho( Ds + rhk * f.sfb[ij], rk, rk1 ) * dzi;
+                    else if (ft) ver = div_rho( -rhkp * f.sft[ij] - cDs, rk, rk1 ) * dzi;
+                    else         ver = div_rho( Ds - cDs, rk, rk1 ) * dzi;
+                    t += hor + ver;
+                }
                 if (DSTORE) dss = t; else f.st[c] = t;
             }
         }
@@ -479,7 +509,7 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
             {
                 __syncthreads();                                   // everyone is done reading the planes that are about to be replaced
                 STAMP(4);
-                st_tile(U[slot(k+1, RU)], pu); st_tile(V[slot(k+1, RU)], pv); st_tile(W[slot(k+2, RW)], pw); st_etile(E[slot(k+2, RE)], pe);
+                st_tile(U[slot(k+1, RU)], pu); st_tile(V[slot(k+1, RU)], pv); st_tile(W[slot(k+2, RW)], pw); if (DIF) st_etile(E[slot(k+2, RE)], pe);
                 if (HAS_S) st_tile(S[0], ps);
                 STAMP(5);
                 __syncthreads();
@@ -518,8 +548,9 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
 #endif
 }
 
+// mode 0: advec_2i5 + diff_smag2 (the fused pass); 1: advec_2i5 only (p may be null); 2: diff_smag2 only
 template<class TF>
-int march_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, int j0, int j1, hipStream_t st)
+int march_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, int j0, int j1, hipStream_t st, int mode = 0)
 {
 #ifndef MHH_MARCH_NJ
 #define MHH_MARCH_NJ 4
@@ -527,15 +558,15 @@ int march_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* 
     constexpr int NJ = MHH_MARCH_NJ;
     const GridDev<TF> gd = make_grid<TF>(g);
     MarchFields<TF> mf;
-    mf.u = cp<TF>(f->u); mf.v = cp<TF>(f->v); mf.w = cp<TF>(f->w); mf.ev = cp<TF>(f->evisc);
+    mf.u = cp<TF>(f->u); mf.v = cp<TF>(f->v); mf.w = cp<TF>(f->w); mf.ev = (mode == 1) ? nullptr : cp<TF>(f->evisc);
     mf.ut = mp<TF>(f->ut); mf.vt = mp<TF>(f->vt); mf.wt = mp<TF>(f->wt);
     const bool has_s = f->nscalars >= 1;
     mf.s = has_s ? cp<TF>(f->s[0]) : nullptr; mf.st = has_s ? mp<TF>(f->st[0]) : nullptr;
     mf.rhoref = cp<TF>(f->rhoref); mf.rhorefh = cp<TF>(f->rhorefh);
     mf.ufb = cp<TF>(f->u_fluxbot); mf.uft = cp<TF>(f->u_fluxtop); mf.vfb = cp<TF>(f->v_fluxbot); mf.vft = cp<TF>(f->v_fluxtop);
     mf.sfb = has_s ? cp<TF>(f->s_fluxbot[0]) : nullptr; mf.sft = has_s ? cp<TF>(f->s_fluxtop[0]) : nullptr;
-    mf.visc = TF(f->visc); mf.svisc = has_s ? TF(f->svisc[0]) : TF(0); mf.tPr = TF(p->tPr); mf.sm = p->surface_model;
-    const bool buoy = has_s && p->buoyancy == 2 && p->th_for_N2 == 0;
+    mf.visc = TF(f->visc); mf.svisc = has_s ? TF(f->svisc[0]) : TF(0); mf.tPr = p ? TF(p->tPr) : TF(1); mf.sm = (p && mode != 1) ? p->surface_model : 0;
+    const bool buoy = mode == 0 && has_s && p->buoyancy == 2 && p->th_for_N2 == 0;
     mf.threfh = buoy ? cp<TF>(p->threfh) : nullptr; mf.grav = buoy ? TF(p->grav) : TF(0);
 #ifndef MHH_MARCH_KC
 #define MHH_MARCH_KC 128
@@ -549,12 +580,18 @@ int march_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* 
     constexpr int VEC = 16 / (int)sizeof(TF);
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
     const char* env = getenv("MHH_MARCH_DMA");
-    const bool aligned = (g->icells % VEC == 0) && al16(f->u) && al16(f->v) && al16(f->w) && al16(f->evisc) && (!has_s || al16(f->s[0]));
+    const bool aligned = (g->icells % VEC == 0) && al16(f->u) && al16(f->v) && al16(f->w) && (mode == 1 || al16(f->evisc)) && (!has_s || al16(f->s[0]));
     const int pb = (env && !strcmp(env, "0")) ? 0 : ((env && !strcmp(env, "4")) || !aligned) ? 4 : 16;
 #define MHH_LAUNCH_MARCH(PBV) do { \
         if (has_s) hipLaunchKernelGGL((rhs25_march_kernel<TF, NJ, true, PBV>),  dim3(nblocks), dim3(64, NJ), 0, st, gd, mf, t); \
         else       hipLaunchKernelGGL((rhs25_march_kernel<TF, NJ, false, PBV>), dim3(nblocks), dim3(64, NJ), 0, st, gd, mf, t); } while (0)
-    if (pb == 16) MHH_LAUNCH_MARCH(16); else if (pb == 4) MHH_LAUNCH_MARCH(4); else MHH_LAUNCH_MARCH(0);
+#define MHH_LAUNCH_MARCH1(PBV, A, D) do { \
+        if (has_s) hipLaunchKernelGGL((rhs25_march_kernel<TF, NJ, true, PBV, A, D>),  dim3(nblocks), dim3(64, NJ), 0, st, gd, mf, t); \
+        else       hipLaunchKernelGGL((rhs25_march_kernel<TF, NJ, false, PBV, A, D>), dim3(nblocks), dim3(64, NJ), 0, st, gd, mf, t); } while (0)
+    if (mode == 0)      { if (pb == 16) MHH_LAUNCH_MARCH(16); else if (pb == 4) MHH_LAUNCH_MARCH(4); else MHH_LAUNCH_MARCH(0); }
+    else if (mode == 1) { if (pb == 16) MHH_LAUNCH_MARCH1(16, true, false); else MHH_LAUNCH_MARCH1(4, true, false); }      // one operator: LDS-DMA forms only
+    else                { if (pb == 16) MHH_LAUNCH_MARCH1(16, false, true); else MHH_LAUNCH_MARCH1(4, false, true); }
+#undef MHH_LAUNCH_MARCH1
 #undef MHH_LAUNCH_MARCH
     MHH_LAUNCH_CHECK();
     return MHH_OK;
@@ -572,6 +609,19 @@ int mhh_rhs25_march_rows(const mhh_grid* g, const mhh_fields* f, const mhh_diff_
 {
     if (g->dtype == MHH_F64) return march_launch<double>(g, f, p, j0, j1, as_stream(stream));
     return march_launch<float>(g, f, p, j0, j1, as_stream(stream));
+}
+
+// Advec_2i5::exec / Diff_smag2::exec on their own, for u, v, w and scalar 0 (inputs validated by the caller): the marching
+// kernel with one operator's terms only -- what the two calls of an unfused time step run.
+int mhh_advec25_march(const mhh_grid* g, const mhh_fields* f, void* stream)
+{
+    if (g->dtype == MHH_F64) return march_launch<double>(g, f, nullptr, -1, -1, as_stream(stream), 1);
+    return march_launch<float>(g, f, nullptr, -1, -1, as_stream(stream), 1);
+}
+int mhh_diff_smag2_march(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, void* stream)
+{
+    if (g->dtype == MHH_F64) return march_launch<double>(g, f, p, -1, -1, as_stream(stream), 2);
+    return march_launch<float>(g, f, p, -1, -1, as_stream(stream), 2);
 }
 
 #ifdef MHH_MARCH_STAMPS

@@ -1,6 +1,7 @@
 // k_rhs.hip -- operator-level entry points: Diff::exec_viscosity, Diff::exec, the fused advec+diff RHS pass,
 // and the max-reductions behind get_cfl / get_dn / check_divergence. gfx950 only.
 #include <cstdlib>
+#include <cstring>
 #include <cstdint>
 #include "k_common.h"
 #include <wave_reduce.h>   // angle form: the CPU emulation build (tests/emul) overrides it by include path
@@ -8,6 +9,7 @@
 using namespace mhh;
 
 int mhh_rhs25_march(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, void* stream);   // k_march.hip
+int mhh_diff_smag2_march(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, void* stream);   // k_march.hip
 int mhh_visc_march(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, const void* th, void* stream);   // k_visc.hip
 int mhh_visc_march_rows(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, const void* th, int j0, int j1, void* stream);
 int mhh_rhs25_march_rows(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, int j0, int j1, void* stream);   // k_march.hip
@@ -216,6 +218,22 @@ MHH_API int mhh_diff_exec(const mhh_grid* g, int scheme, const mhh_fields* f, co
     }
     MHH_REQUIRE(scheme == MHH_DIFF_SMAG2 && p, "scheme must be 2, 4 or 22 (with params)");
     const int sm = p->surface_model;
+    // u, v, w and the first scalar in one pass of the marching kernel with the diffusive terms only (k_march.hip; same bits
+    // as the per-field kernels, which MHH_DIFF22_IMPL=cell selects); further scalars per field. Needs the advec_2i5 halo
+    // (the tiles are cut for it): other layouts take the per-field kernels.
+    const char* impl = getenv("MHH_DIFF22_IMPL");
+    if (!(impl && !strcmp(impl, "cell")) && g && g->igc >= 3 && g->jgc >= 3 && g->kgc >= 1 && g->ktot >= 6)
+    {
+        if (int e = check_grid(g)) return e;
+        MHH_REQUIRE(f->u && f->v && f->w && f->ut && f->vt && f->wt && f->evisc && f->rhoref && f->rhorefh, "null field");
+        if (sm) MHH_REQUIRE(f->u_fluxbot && f->u_fluxtop && f->v_fluxbot && f->v_fluxtop, "surface fluxes");
+        for (int n=0; n<f->nscalars; ++n) MHH_REQUIRE(f->s[n] && f->st[n] && (!sm || (f->s_fluxbot[n] && f->s_fluxtop[n])), "null scalar / scalar surface fluxes");
+        mhh_fields fm = *f; fm.nscalars = f->nscalars > 0 ? 1 : 0;
+        if (int e = mhh_diff_smag2_march(g, &fm, p, stream)) return e;
+        for (int n=1; n<f->nscalars; ++n)
+            if (int e = mhh_smag2_diff_c(g, sm, f->st[n], f->s[n], f->evisc, f->s_fluxbot[n], f->s_fluxtop[n], f->rhoref, f->rhorefh, p->tPr, f->svisc[n], stream)) return e;
+        return MHH_OK;
+    }
     if (int e = mhh_smag2_diff_u(g, sm, f->ut, f->u, f->v, f->w, f->evisc, f->u_fluxbot, f->u_fluxtop, f->rhoref, f->rhorefh, f->visc, stream)) return e;
     if (int e = mhh_smag2_diff_v(g, sm, f->vt, f->u, f->v, f->w, f->evisc, f->v_fluxbot, f->v_fluxtop, f->rhoref, f->rhorefh, f->visc, stream)) return e;
     if (int e = mhh_smag2_diff_w(g, f->wt, f->u, f->v, f->w, f->evisc, f->rhoref, f->rhorefh, f->visc, stream)) return e;

@@ -2,6 +2,8 @@
 // granularity (advec_u/v/w/s, diff_c/w, smag2 pieces, boundary_cyclic, calc_N2, rk substep) and their C-ABI
 // entry points. gfx950 only. The fused multi-tendency RHS kernels live in k_rhs.hip.
 #include <cstdarg>
+#include <cstdlib>
+#include <cstring>
 #include "k_common.h"
 
 namespace mhh
@@ -251,10 +253,31 @@ MHH_API int mhh_advec_s_lim(const mhh_grid* g, void* st, const void* sc, const v
 #undef CALL
 }
 
+int mhh_advec25_march(const mhh_grid* g, const mhh_fields* f, void* stream);                    // k_march.hip
 MHH_API int mhh_advec_exec(const mhh_grid* g, int scheme, const mhh_fields* f, void* stream)
 {
     MHH_REQUIRE(f != nullptr, "fields");
     MHH_REQUIRE(f->nscalars >= 0 && f->nscalars <= MHH_MAX_SCALARS, "nscalars");
+    // advec_2i5: u, v, w and the first (unlimited) scalar in one pass of the marching kernel with the advective terms only
+    // (k_march.hip; same bits as the per-field kernels, which MHH_ADVEC25_IMPL=cell selects); further scalars per field.
+    const char* impl = getenv("MHH_ADVEC25_IMPL");
+    if (scheme == MHH_ADVEC_2I5 && !(impl && !strcmp(impl, "cell")))
+    {
+        if (int e = check_grid(g)) return e;
+        if (int e = check_advec(g, scheme)) return e;
+        MHH_REQUIRE(f->u && f->v && f->w && f->ut && f->vt && f->wt && f->rhoref && f->rhorefh, "null field");
+        for (int n=0; n<f->nscalars; ++n) MHH_REQUIRE(f->s[n] && f->st[n], "null scalar");
+        mhh_fields fm = *f;
+        const bool s0 = f->nscalars > 0 && !f->s_fluxlimit[0];
+        fm.nscalars = s0 ? 1 : 0;
+        if (int e = mhh_advec25_march(g, &fm, stream)) return e;
+        for (int n=(s0 ? 1 : 0); n<f->nscalars; ++n)
+        {
+            if (f->s_fluxlimit[n]) { if (int e = mhh_advec_s_lim(g, f->st[n], f->s[n], f->u, f->v, f->w, f->rhoref, f->rhorefh, stream)) return e; }
+            else if (int e = mhh_advec_s(g, scheme, f->st[n], f->s[n], f->u, f->v, f->w, f->rhoref, f->rhorefh, stream)) return e;
+        }
+        return MHH_OK;
+    }
     if (int e = mhh_advec_u(g, scheme, f->ut, f->u, f->v, f->w, f->rhoref, f->rhorefh, stream)) return e;
     if (int e = mhh_advec_v(g, scheme, f->vt, f->u, f->v, f->w, f->rhoref, f->rhorefh, stream)) return e;
     if (int e = mhh_advec_w(g, scheme, f->wt, f->u, f->v, f->w, f->rhoref, f->rhorefh, stream)) return e;

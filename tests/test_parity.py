@@ -495,6 +495,35 @@ def test_fused_rhs_on_minimal_and_ragged_grids(be, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_advec25_and_diff_smag2_alone_marching_form_equals_per_field_kernels(be, dtype):
+    """Advec::exec (2i5) and Diff::exec (smag2) as separate calls run the marching kernel with one operator's terms
+    (u, v, w and the first unlimited scalar; further / flux-limited scalars per field): the bits of the per-field cell
+    kernels after each of the two calls, on aligned, unaligned, ragged and minimal grids, with and without surface model."""
+    for shape, sm, lim in [((70, 10, 12), 1, (0, 0)), ((17, 9, 8), 0, (0, 1)), ((8, 6, 6), 1, (1, 0)), ((130, 3, 6), 1, (0, 0))]:
+        g = cm.grid_2nd(*shape, gc=(3, 3, 2), dtype=dtype)
+        c = cm.Case(g, nscalars=2)
+        p = capi.MhhDiffParams(); p.cs = 0.23; p.tPr = 1./3.; p.surface_model = sm
+        out = {}
+        for impl in ("march", "cell"):
+            d = B.DevCase(be, c); f = d.fields()
+            f.s_fluxlimit[0], f.s_fluxlimit[1] = lim
+            if impl == "cell":
+                os.environ["MHH_ADVEC25_IMPL"] = "cell"; os.environ["MHH_DIFF22_IMPL"] = "cell"
+            try:
+                B.ok(be, be.lib.mhh_advec_exec(d.G, cm.ADVEC_2I5, C.byref(f), be.stream))
+                adv = [be.host(x) for x in (d.ut, d.vt, d.wt, d.st[0], d.st[1])]
+                B.ok(be, be.lib.mhh_diff_exec(d.G, cm.DIFF_SMAG2, C.byref(f), C.byref(p), be.stream))
+                dif = [be.host(x) for x in (d.ut, d.vt, d.wt, d.st[0], d.st[1])]
+            finally:
+                os.environ.pop("MHH_ADVEC25_IMPL", None); os.environ.pop("MHH_DIFF22_IMPL", None)
+            out[impl] = (adv, dif)
+        for stage, nm in ((0, "advec"), (1, "diff")):
+            for a, b, fld in zip(out["march"][stage], out["cell"][stage], ("ut", "vt", "wt", "st0", "st1")):
+                assert same(a, b), (shape, nm, fld, cm.ulp_diff(a, b))
+        assert not np.array_equal(out["march"][0][0], c.ut) and not np.array_equal(out["march"][1][0], out["march"][0][0])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_rhs25_march_copy_forms_agree(be, dtype):
     """The three plane-copy forms of k_march.hip (16-byte LDS-DMA, 4-byte LDS-DMA, register-staged) and the cell kernel
     give the same bits; layouts that are not 16-byte aligned take the 4-byte form by themselves."""
@@ -509,6 +538,8 @@ def test_rhs25_march_copy_forms_agree(be, dtype):
             key, val = ("MHH_RHS25_IMPL", "cell") if form == "cell" else ("MHH_MARCH_DMA", form)
             if form != "default":
                 os.environ[key] = val
+            if form == "cell":
+                os.environ["MHH_ADVEC25_IMPL"] = "cell"; os.environ["MHH_DIFF22_IMPL"] = "cell"
             try:
                 if form == "cell":
                     B.ok(be, be.lib.mhh_advec_exec(d.G, adv, C.byref(f), be.stream))
@@ -516,7 +547,7 @@ def test_rhs25_march_copy_forms_agree(be, dtype):
                 else:
                     B.ok(be, be.lib.mhh_rhs_exec(d.G, adv, dif, C.byref(f), C.byref(p), be.stream))
             finally:
-                os.environ.pop(key, None)
+                os.environ.pop(key, None); os.environ.pop("MHH_ADVEC25_IMPL", None); os.environ.pop("MHH_DIFF22_IMPL", None)
             out[form] = [be.host(x) for x in (d.ut, d.vt, d.wt, d.st[0])]
         for form in ("4", "0", "cell"):
             for a, b, nm in zip(out["default"], out[form], ("ut", "vt", "wt", "st")):
