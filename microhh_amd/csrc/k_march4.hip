@@ -53,7 +53,8 @@ template<class TF> __device__ __forceinline__ void shift7(TF (&w)[7], TF nw)
 #define MHH_MARCH4_KC 64
 #endif
 
-template<class TF, int NJ, int PB>
+// ADV / DIF: both operators (the fused pass) or one of them (Advec_4::exec / Diff_4::exec called separately: same body, same bits)
+template<class TF, int NJ, int PB, bool ADV = true, bool DIF = true>
 __global__ void __launch_bounds__(64*NJ, MHH_MARCH4_OCC) rhs44_march_kernel(const GridDev<TF> g, const March4Fields<TF> f, const MarchTiling mt)
 {
     constexpr int AL = (PB == 16) ? 16 / (int)sizeof(TF) : 1;
@@ -108,8 +109,8 @@ __global__ void __launch_bounds__(64*NJ, MHH_MARCH4_OCC) rhs44_march_kernel(cons
     const bool dim3 = g.dim3;
     auto both = [&](TF t, const TF ad[3], const TF df[3]) -> TF
     {
-        t -= ad[0]; if (dim3) t -= ad[1]; t -= ad[2];
-        t += df[0]; if (dim3) t += df[1]; t += df[2];
+        if constexpr (ADV) { t -= ad[0]; if (dim3) t -= ad[1]; t -= ad[2]; }
+        if constexpr (DIF) { t += df[0]; if (dim3) t += df[1]; t += df[2]; }
         return t;
     };
 
@@ -137,8 +138,8 @@ __global__ void __launch_bounds__(64*NJ, MHH_MARCH4_OCC) rhs44_march_kernel(cons
         {
             const bool botw = (k == g.kstart+1);
             const TF gw4[4] = {uniform_load(g.dzi4, k-2), uniform_load(g.dzi4, k-1), uniform_load(g.dzi4, k), uniform_load(g.dzi4, k+1)};
-            advec4_mom_v<2>(ad, Wv, Uv, Vv, Wv, botw, top, dxi, dyi, uniform_load(g.dzhi4, k), dim3);
-            diff4_v(df, Wv, botw, top, f.visc, g.dxidxi_t, g.dyidyi_t, gw4, uniform_load(g.dzhi4, k), dim3);
+            if constexpr (ADV) advec4_mom_v<2>(ad, Wv, Uv, Vv, Wv, botw, top, dxi, dyi, uniform_load(g.dzhi4, k), dim3);
+            if constexpr (DIF) diff4_v(df, Wv, botw, top, f.visc, g.dxidxi_t, g.dyidyi_t, gw4, uniform_load(g.dzhi4, k), dim3);
             f.wt[c] = both(TPREF ? tcw : f.wt[c], ad, df);
         }
         if (more)
@@ -150,11 +151,11 @@ __global__ void __launch_bounds__(64*NJ, MHH_MARCH4_OCC) rhs44_march_kernel(cons
         if (active)
         {
             const TF gc4[4] = {uniform_load(g.dzhi4, k-1), uniform_load(g.dzhi4, k), uniform_load(g.dzhi4, k+1), uniform_load(g.dzhi4, k+2)};
-            advec4_mom_v<0>(ad, Uv, Uv, Vv, Wv, bot, top, dxi, dyi, uniform_load(g.dzi4, k), dim3);
-            diff4_v(df, Uv, bot, top, f.visc, g.dxidxi_d, g.dyidyi_d, gc4, uniform_load(g.dzi4, k), dim3);
+            if constexpr (ADV) advec4_mom_v<0>(ad, Uv, Uv, Vv, Wv, bot, top, dxi, dyi, uniform_load(g.dzi4, k), dim3);
+            if constexpr (DIF) diff4_v(df, Uv, bot, top, f.visc, g.dxidxi_d, g.dyidyi_d, gc4, uniform_load(g.dzi4, k), dim3);
             ut_pending = both(TPREF ? tcu : f.ut[c], ad, df);
-            advec4_mom_v<1>(ad, Vv, Uv, Vv, Wv, bot, top, dxi, dyi, uniform_load(g.dzi4, k), dim3);
-            diff4_v(df, Vv, bot, top, f.visc, g.dxidxi_d, g.dyidyi_d, gc4, uniform_load(g.dzi4, k), dim3);
+            if constexpr (ADV) advec4_mom_v<1>(ad, Vv, Uv, Vv, Wv, bot, top, dxi, dyi, uniform_load(g.dzi4, k), dim3);
+            if constexpr (DIF) diff4_v(df, Vv, bot, top, f.visc, g.dxidxi_d, g.dyidyi_d, gc4, uniform_load(g.dzi4, k), dim3);
             vt_pending = both(TPREF ? tcv : f.vt[c], ad, df);
             c_pending = c;
         }
@@ -169,15 +170,20 @@ __global__ void __launch_bounds__(64*NJ, MHH_MARCH4_OCC) rhs44_march_kernel(cons
 #define MHH_MARCH4_NJ 4
 #endif
 template<class TF>
-int march4_launch(const mhh_grid* g, const mhh_fields* f, int pb, hipStream_t st)
+int march4_launch(const mhh_grid* g, const mhh_fields* f, int pb, hipStream_t st, int mode = 0)      // 0: both, 1: advec_4, 2: diff_4
 {
     constexpr int NJ = MHH_MARCH4_NJ;
     March4Fields<TF> mf;
     mf.u = cp<TF>(f->u); mf.v = cp<TF>(f->v); mf.w = cp<TF>(f->w);
     mf.ut = mp<TF>(f->ut); mf.vt = mp<TF>(f->vt); mf.wt = mp<TF>(f->wt); mf.visc = TF(f->visc);
     const MarchTiling t = make_march_tiling(g, NJ, MHH_MARCH4_KC);
-    if (pb == 16) hipLaunchKernelGGL((rhs44_march_kernel<TF, NJ, 16>), dim3(march_blocks(t)), dim3(64, NJ), 0, st, make_grid<TF>(g), mf, t);
-    else          hipLaunchKernelGGL((rhs44_march_kernel<TF, NJ, 4>),  dim3(march_blocks(t)), dim3(64, NJ), 0, st, make_grid<TF>(g), mf, t);
+    const dim3 nb(march_blocks(t)), bs(64, NJ);
+    const GridDev<TF> gd = make_grid<TF>(g);
+#define MHH_L4(PBV, A, D) hipLaunchKernelGGL((rhs44_march_kernel<TF, NJ, PBV, A, D>), nb, bs, 0, st, gd, mf, t)
+    if (mode == 0)      { if (pb == 16) MHH_L4(16, true, true);  else MHH_L4(4, true, true); }
+    else if (mode == 1) { if (pb == 16) MHH_L4(16, true, false); else MHH_L4(4, true, false); }
+    else                { if (pb == 16) MHH_L4(16, false, true); else MHH_L4(4, false, true); }
+#undef MHH_L4
     MHH_LAUNCH_CHECK();
     return MHH_OK;
 }
@@ -188,7 +194,12 @@ MHH_API unsigned long long mhh_stat_rhs44_march_launches(void) { return g_rhs44_
 
 // Entry used by mhh_rhs_exec for (advec_4, diff_4): u, v, w only (scalars take the per-field kernels). Returns 1 when the
 // marching kernel ran, 0 when it is switched off (MHH_RHS44_IMPL=cell), < 0 on error (-code).
-int mhh_rhs44_march(const mhh_grid* g, const mhh_fields* f, void* stream)
+static int rhs44_march_mode(const mhh_grid* g, const mhh_fields* f, void* stream, int mode);
+int mhh_rhs44_march(const mhh_grid* g, const mhh_fields* f, void* stream) { return rhs44_march_mode(g, f, stream, 0); }
+// Advec_4::exec / Diff_4::exec on their own for u, v, w (same return convention)
+int mhh_advec4_march(const mhh_grid* g, const mhh_fields* f, void* stream) { return rhs44_march_mode(g, f, stream, 1); }
+int mhh_diff4_march(const mhh_grid* g, const mhh_fields* f, void* stream) { return rhs44_march_mode(g, f, stream, 2); }
+static int rhs44_march_mode(const mhh_grid* g, const mhh_fields* f, void* stream, int mode)
 {
     { const char* e = getenv("MHH_RHS44_IMPL"); if (e && !strcmp(e, "cell")) return 0; }
     const int vec = (g->dtype == MHH_F64) ? 2 : 4;
@@ -197,6 +208,6 @@ int mhh_rhs44_march(const mhh_grid* g, const mhh_fields* f, void* stream)
     // 16-byte pieces need 16-byte aligned rows and tile origin (i0 - 3 = igc - 3 + 64*bx); other layouts copy in 4-byte pieces
     const int pb = (g->icells % vec == 0 && (g->igc - 3) % vec == 0 && al16(f->u) && al16(f->v) && al16(f->w)) ? 16 : 4;
     ++g_rhs44_march_launches;
-    const int rc = (g->dtype == MHH_F64) ? march4_launch<double>(g, f, pb, as_stream(stream)) : march4_launch<float>(g, f, pb, as_stream(stream));
+    const int rc = (g->dtype == MHH_F64) ? march4_launch<double>(g, f, pb, as_stream(stream), mode) : march4_launch<float>(g, f, pb, as_stream(stream), mode);
     return rc == MHH_OK ? 1 : -rc;
 }

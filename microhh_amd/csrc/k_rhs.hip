@@ -13,7 +13,8 @@ int mhh_diff_smag2_march(const mhh_grid* g, const mhh_fields* f, const mhh_diff_
 int mhh_visc_march(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, const void* th, void* stream);   // k_visc.hip
 int mhh_visc_march_rows(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, const void* th, int j0, int j1, void* stream);
 int mhh_rhs25_march_rows(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, int j0, int j1, void* stream);   // k_march.hip
-int mhh_rhs44_march(const mhh_grid* g, const mhh_fields* f, void* stream);                                           // k_march4.hip
+int mhh_rhs44_march(const mhh_grid* g, const mhh_fields* f, void* stream);
+int mhh_diff4_march(const mhh_grid* g, const mhh_fields* f, void* stream);                                           // k_march4.hip
 
 // =======================================================================================================
 // Max reductions (calc_cfl / calc_dnmul / calc_divergence + Master::max). All integrands are |.| >= 0, so the
@@ -209,9 +210,21 @@ MHH_API int mhh_diff_exec(const mhh_grid* g, int scheme, const mhh_fields* f, co
     if (scheme == MHH_DIFF_2 || scheme == MHH_DIFF_4)
     {
         const int o = (scheme == MHH_DIFF_2) ? 2 : 4;
-        if (int e = mhh_diff_c(g, o, f->ut, f->u, f->visc, stream)) return e;
-        if (int e = mhh_diff_c(g, o, f->vt, f->v, f->visc, stream)) return e;
-        if (int e = mhh_diff_w(g, o, f->wt, f->w, f->visc, stream)) return e;
+        bool uvw_done = false;
+        if (o == 4 && g && g->igc >= 3 && g->jgc >= 3 && g->kgc >= 3)     // u, v, w in one pass of the 4th-order marching kernel (diffusive terms only)
+        {
+            if (int e = check_grid(g)) return e;
+            MHH_REQUIRE(f->u && f->v && f->w && f->ut && f->vt && f->wt, "null field");
+            const int rc = mhh_diff4_march(g, f, stream);
+            if (rc < 0) return -rc;
+            uvw_done = (rc == 1);
+        }
+        if (!uvw_done)
+        {
+            if (int e = mhh_diff_c(g, o, f->ut, f->u, f->visc, stream)) return e;
+            if (int e = mhh_diff_c(g, o, f->vt, f->v, f->visc, stream)) return e;
+            if (int e = mhh_diff_w(g, o, f->wt, f->w, f->visc, stream)) return e;
+        }
         for (int n=0; n<f->nscalars; ++n)
             if (int e = mhh_diff_c(g, o, f->st[n], f->s[n], f->svisc[n], stream)) return e;
         return MHH_OK;

@@ -254,6 +254,7 @@ MHH_API int mhh_advec_s_lim(const mhh_grid* g, void* st, const void* sc, const v
 }
 
 int mhh_advec25_march(const mhh_grid* g, const mhh_fields* f, void* stream);                    // k_march.hip
+int mhh_advec4_march(const mhh_grid* g, const mhh_fields* f, void* stream);                     // k_march4.hip
 MHH_API int mhh_advec_exec(const mhh_grid* g, int scheme, const mhh_fields* f, void* stream)
 {
     MHH_REQUIRE(f != nullptr, "fields");
@@ -278,9 +279,21 @@ MHH_API int mhh_advec_exec(const mhh_grid* g, int scheme, const mhh_fields* f, v
         }
         return MHH_OK;
     }
-    if (int e = mhh_advec_u(g, scheme, f->ut, f->u, f->v, f->w, f->rhoref, f->rhorefh, stream)) return e;
-    if (int e = mhh_advec_v(g, scheme, f->vt, f->u, f->v, f->w, f->rhoref, f->rhorefh, stream)) return e;
-    if (int e = mhh_advec_w(g, scheme, f->wt, f->u, f->v, f->w, f->rhoref, f->rhorefh, stream)) return e;
+    bool uvw_done = false;
+    if (scheme == MHH_ADVEC_4)           // u, v, w in one pass of the 4th-order marching kernel (advective terms only); scalars per field
+    {
+        if (int e = check_advec(g, scheme)) return e;
+        MHH_REQUIRE(f->u && f->v && f->w && f->ut && f->vt && f->wt, "null field");
+        const int rc = mhh_advec4_march(g, f, stream);
+        if (rc < 0) return -rc;
+        uvw_done = (rc == 1);
+    }
+    if (!uvw_done)
+    {
+        if (int e = mhh_advec_u(g, scheme, f->ut, f->u, f->v, f->w, f->rhoref, f->rhorefh, stream)) return e;
+        if (int e = mhh_advec_v(g, scheme, f->vt, f->u, f->v, f->w, f->rhoref, f->rhorefh, stream)) return e;
+        if (int e = mhh_advec_w(g, scheme, f->wt, f->u, f->v, f->w, f->rhoref, f->rhorefh, stream)) return e;
+    }
     for (int n=0; n<f->nscalars; ++n)
     {
         if (f->s_fluxlimit[n])

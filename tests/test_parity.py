@@ -524,6 +524,33 @@ def test_advec25_and_diff_smag2_alone_marching_form_equals_per_field_kernels(be,
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_advec4_and_diff4_alone_marching_form_equals_per_field_kernels(be, dtype):
+    """Advec_4::exec and Diff_4::exec as separate calls: u, v, w through the 4th-order marching kernel with one operator's
+    terms, scalars per field -- the bits of the per-field kernels (MHH_RHS44_IMPL=cell) after each call; 3-D and 2-D grids."""
+    for shape in [(70, 10, 12), (17, 9, 8), (12, 1, 8), (66, 5, 9)]:
+        g = cm.grid_4th(*shape, dtype=dtype)
+        c = cm.Case(g, nscalars=1)
+        out = {}
+        for impl in ("march", "cell"):
+            d = B.DevCase(be, c); f = d.fields()
+            if impl == "cell":
+                os.environ["MHH_RHS44_IMPL"] = "cell"
+            try:
+                n0 = be.lib.mhh_stat_rhs44_march_launches()
+                B.ok(be, be.lib.mhh_advec_exec(d.G, cm.ADVEC_4, C.byref(f), be.stream))
+                adv = [be.host(x) for x in (d.ut, d.vt, d.wt, d.st[0])]
+                B.ok(be, be.lib.mhh_diff_exec(d.G, cm.DIFF_4, C.byref(f), None, be.stream))
+                dif = [be.host(x) for x in (d.ut, d.vt, d.wt, d.st[0])]
+                assert be.lib.mhh_stat_rhs44_march_launches() - n0 == (2 if impl == "march" else 0)
+            finally:
+                os.environ.pop("MHH_RHS44_IMPL", None)
+            out[impl] = (adv, dif)
+        for stage, nm in ((0, "advec"), (1, "diff")):
+            for a, b, fld in zip(out["march"][stage], out["cell"][stage], ("ut", "vt", "wt", "st")):
+                assert same(a, b), (shape, nm, fld, cm.ulp_diff(a, b))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_rhs25_march_copy_forms_agree(be, dtype):
     """The three plane-copy forms of k_march.hip (16-byte LDS-DMA, 4-byte LDS-DMA, register-staged) and the cell kernel
     give the same bits; layouts that are not 16-byte aligned take the 4-byte form by themselves."""
