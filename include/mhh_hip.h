@@ -300,6 +300,11 @@ void* mhh_pres_slab_packed(mhh_pres_slab_plan* plan);   /* plan-owned packed-div
 int mhh_pres_fwd_x_pack       (mhh_pres_slab_plan* plan, const mhh_grid* g, void* p_packed, void* sendbuf, void* stream);
 int mhh_pres_fwd_y_solve_bwd_y(mhh_pres_slab_plan* plan, const mhh_grid* g, void* recvbuf, void* sendbuf, void* stream);
 int mhh_pres_bwd_x_unpack     (mhh_pres_slab_plan* plan, const mhh_grid* g, void* recvbuf, const mhh_fields* f, void* stream);
+/* the same with Pres_2::output (src/pres_2.cxx:365-387) in the unpack kernel, for everything but vt on the southernmost row
+ * (its p[j-1] lives on the south neighbour): exchange the one-row halo of p, then mhh_pres_output_south_row. Same bits as
+ * mhh_pres_bwd_x_unpack + halo + mhh_pres_output_order, one pass over p, ut, vt, wt less. */
+int mhh_pres_bwd_x_unpack_output(mhh_pres_slab_plan* plan, const mhh_grid* g, void* recvbuf, const mhh_fields* f, void* stream);
+int mhh_pres_output_south_row (const mhh_grid* g, const mhh_fields* f, void* stream);
 
 /* ---- Vertical ghost cells --------------------------------------------------------------
  * Boundary::set_ghost_cells: calc_ghost_cells_{bot,top}_{2nd,4th} (src/boundary.cxx:686-836); bc 0 = Dirichlet

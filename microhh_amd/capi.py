@@ -96,6 +96,8 @@ SIGNATURES = {
     "mhh_pres_fwd_x_pack": (ci, [PLAN, GP, vp, vp, vp]),
     "mhh_pres_fwd_y_solve_bwd_y": (ci, [PLAN, GP, vp, vp, vp]),
     "mhh_pres_bwd_x_unpack": (ci, [PLAN, GP, vp, FP, vp]),
+    "mhh_pres_bwd_x_unpack_output": (ci, [PLAN, GP, vp, FP, vp]),
+    "mhh_pres_output_south_row": (ci, [GP, FP, vp]),
 }
 
 

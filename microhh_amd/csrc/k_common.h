@@ -147,4 +147,10 @@ inline int launch_interior(hipStream_t st, const GridDev<TF>& g, int k0, int k1,
 
 #define MHH_DISPATCH(g, CALL) ((g)->dtype == MHH_F64 ? CALL(double) : CALL(float))
 
+// The inverse transform's normalisation, value / jtot / itot (src/fft.cxx). Where both extents are powers of two (POW2) the
+// two divisions are two multiplications by the exact reciprocals: the same correctly rounded results, a tenth of the issue slots.
+template<bool POW2, class TF>
+__device__ __forceinline__ TF fft_norm(TF v, int itot, int jtot, TF ri, TF rj) { return POW2 ? (v * rj) * ri : v / jtot / itot; }
+static inline bool is_pow2(int n) { return n > 0 && (n & (n-1)) == 0; }
+
 } // namespace mhh

@@ -554,11 +554,6 @@ __global__ void __launch_bounds__(128) hdma_solve_kernel(TF* __restrict__ p, con
 // unpack (src/pres_2.cxx:333-362, src/pres_4.cxx:481-528): normalise, ghosted layout, vertical ghost rows,
 // periodic halo -- one kernel over icells x jcells x (kmax + vertical ghosts), reading with wrapped indices.
 // =======================================================================================================
-// The transform's normalisation, value / jtot / itot (src/fft.cxx). Where both extents are powers of two (POW2) the two
-// divisions are two multiplications by the exact reciprocals: the same correctly rounded results, a tenth of the issue slots.
-template<bool POW2, class TF>
-__device__ __forceinline__ TF fft_norm(TF v, int itot, int jtot, TF ri, TF rj) { return POW2 ? (v * rj) * ri : v / jtot / itot; }
-static inline bool is_pow2(int n) { return n > 0 && (n & (n-1)) == 0; }
 // Block b of a launch runs on XCD b % 8 (round-robin dispatch). chunk_of_block deals the chunks of a plane so that every
 // XCD owns ONE contiguous run of them: the row j-1 a cell reads then sits in the L2 of the XCD that read it as row j
 // (unpack+output at 512^3: HBM fetch 6.8 -> see profiles, r1j).

@@ -411,6 +411,49 @@ __global__ void __launch_bounds__(256) unpack_slab_kernel(TF* __restrict__ p, co
     p[(size_t)i + (size_t)(jl + jgc)*icells + (size_t)kd*icells*jcells] = val;
 }
 
+// unpack and Pres_2::output in one pass on a slab (as unpack_out2_kernel of k_pres.hip): p of the rank's own rows, and on
+// interior cells ut, wt and -- for every row but the southernmost, whose p[j-1] lives on the south neighbour -- vt, with the
+// neighbours re-normalised from the packed solution (the stored values). The southernmost row of vt follows the one-row
+// halo exchange of p (pres_out_south_row_kernel).
+template<bool POW2, class TF>
+__global__ void __launch_bounds__(256) unpack_out_slab_kernel(TF* __restrict__ p, const TF* __restrict__ packed,
+                                                              TF* __restrict__ ut, TF* __restrict__ vt, TF* __restrict__ wt, const TF* __restrict__ dzhi,
+                                                              TF dxi, TF dyi, int itot, int jtot, int jmax, int kmax, int igc, int jgc, int kgc, int icells, int jcells)
+{
+    const int i = blockIdx.x*256 + threadIdx.x;
+    const int jl = blockIdx.y, kz = blockIdx.z;
+    if (i >= icells) return;
+    const int kd = (kz < kmax) ? kz + kgc : kgc - 1;
+    const int ks = (kz < kmax) ? kz : 0;
+    int is = (i - igc) % itot; if (is < 0) is += itot;
+    const size_t ijm = (size_t)itot*jmax;
+    const TF ri = TF(1)/TF(itot), rj = TF(1)/TF(jtot);
+    const TF pc = fft_norm<POW2>(packed[(size_t)is + (size_t)jl*itot + (size_t)ks*ijm], itot, jtot, ri, rj);
+    const size_t c = (size_t)i + (size_t)(jl + jgc)*icells + (size_t)kd*icells*jcells;
+    p[c] = pc;
+    if (kz < kmax && i >= igc && i < igc + itot)
+    {
+        const int iw = (is == 0) ? itot-1 : is-1;
+        const TF pw = fft_norm<POW2>(packed[(size_t)iw + (size_t)jl*itot + (size_t)ks*ijm], itot, jtot, ri, rj);
+        const TF pb = (ks == 0) ? pc : fft_norm<POW2>(packed[(size_t)is + (size_t)jl*itot + (size_t)(ks-1)*ijm], itot, jtot, ri, rj);
+        ut[c] -= (pc - pw) * dxi;
+        if (jl > 0)
+        {
+            const TF ps = fft_norm<POW2>(packed[(size_t)is + (size_t)(jl-1)*itot + (size_t)ks*ijm], itot, jtot, ri, rj);
+            vt[c] -= (pc - ps) * dyi;
+        }
+        wt[c] -= (pc - pb) * dzhi[kd];
+    }
+}
+template<class TF>
+__global__ void __launch_bounds__(256) pres_out_south_row_kernel(TF* __restrict__ vt, const TF* __restrict__ p, TF dyi, int istart, int iend, int jstart, int kstart, int icells, int ijcells)
+{
+    const int i = istart + blockIdx.x*256 + threadIdx.x;
+    if (i >= iend) return;
+    const size_t c = (size_t)i + (size_t)jstart*icells + (size_t)(kstart + blockIdx.y)*ijcells;
+    vt[c] -= (p[c] - p[c-icells]) * dyi;
+}
+
 static int slab_match(const mhh_pres_slab_plan* P, const mhh_grid* g)
 {
     if (int e = check_grid(g)) return e;
@@ -493,6 +536,43 @@ MHH_API int mhh_pres_bwd_x_unpack(mhh_pres_slab_plan* P, const mhh_grid* g, void
         MHH_FFT_TRY(rocfft_execute(P->bx, in, out, P->info));
         hipLaunchKernelGGL(unpack_slab_kernel<float>, ug, dim3(256), 0, st, mp<float>(f->p), cp<float>(P->packed), g->itot, g->jtot, g->jmax, g->kmax, g->igc, g->jgc, g->kgc, g->icells, g->jcells);
     }
+    MHH_LAUNCH_CHECK();
+    return MHH_OK;
+}
+// stage 3, fused form: inverse x transform, then unpack + Pres_2::output in one kernel for everything but vt on the southernmost
+// row; the caller exchanges the one-row halo of p and finishes with mhh_pres_output_south_row.
+MHH_API int mhh_pres_bwd_x_unpack_output(mhh_pres_slab_plan* P, const mhh_grid* g, void* recvbuf, const mhh_fields* f, void* stream)
+{
+    if (int e = slab_match(P, g)) return e;
+    MHH_REQUIRE(recvbuf && f && f->p && f->ut && f->vt && f->wt, "buffers");
+    hipStream_t st = as_stream(stream);
+    MHH_FFT_TRY(rocfft_execution_info_set_stream(P->info, st));
+    dim3 grid((P->npy*P->nxb + 255)/256, P->jmax, P->ktot);
+    dim3 ug((g->icells + 255)/256, g->jmax, g->kmax + 1);
+    void* in[1] = {P->specx}; void* out[1] = {P->packed};
+    const bool pow2 = is_pow2(g->itot) && is_pow2(g->jtot);
+#define CALL(TF) [&]{ const GridDev<TF> gd = make_grid<TF>(g); \
+        hipLaunchKernelGGL((xbuf_x_kernel<TF, false>), grid, dim3(256), 0, st, (C2<TF>*)P->specx, (C2<TF>*)recvbuf, P->nxh, P->nxb, P->jmax, P->ktot, P->npy); \
+        if (hipGetLastError() != hipSuccess) return (int)MHH_EHIP; \
+        if (rocfft_execute(P->bx, in, out, P->info) != rocfft_status_success) return (int)MHH_EFFT; \
+        if (pow2) hipLaunchKernelGGL((unpack_out_slab_kernel<true, TF>), ug, dim3(256), 0, st, mp<TF>(f->p), cp<TF>(P->packed), mp<TF>(f->ut), mp<TF>(f->vt), mp<TF>(f->wt), gd.dzhi, \
+                           gd.dxi_t, gd.dyi_t, g->itot, g->jtot, g->jmax, g->kmax, g->igc, g->jgc, g->kgc, g->icells, g->jcells); \
+        else hipLaunchKernelGGL((unpack_out_slab_kernel<false, TF>), ug, dim3(256), 0, st, mp<TF>(f->p), cp<TF>(P->packed), mp<TF>(f->ut), mp<TF>(f->vt), mp<TF>(f->wt), gd.dzhi, \
+                           gd.dxi_t, gd.dyi_t, g->itot, g->jtot, g->jmax, g->kmax, g->igc, g->jgc, g->kgc, g->icells, g->jcells); return (int)MHH_OK; }()
+    if (int e = MHH_DISPATCH(g, CALL)) { set_error("pres_bwd_x_unpack_output: launch / FFT error"); return e; }
+#undef CALL
+    MHH_LAUNCH_CHECK();
+    return MHH_OK;
+}
+MHH_API int mhh_pres_output_south_row(const mhh_grid* g, const mhh_fields* f, void* stream)
+{
+    if (int e = check_grid(g)) return e;
+    MHH_REQUIRE(f && f->p && f->vt && g->jgc >= 1, "null field");
+    dim3 grid((g->imax + 255)/256, g->kmax);
+#define CALL(TF) [&]{ const GridDev<TF> gd = make_grid<TF>(g); \
+        hipLaunchKernelGGL(pres_out_south_row_kernel<TF>, grid, dim3(256), 0, as_stream(stream), mp<TF>(f->vt), cp<TF>(f->p), gd.dyi_t, g->istart, g->iend, g->jstart, g->kstart, g->icells, g->ijcells); return (int)MHH_OK; }()
+    if (int e = MHH_DISPATCH(g, CALL)) return e;
+#undef CALL
     MHH_LAUNCH_CHECK();
     return MHH_OK;
 }

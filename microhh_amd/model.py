@@ -81,7 +81,7 @@ class HotPath:
         self._host_staged = False
         if self.on_gpu and npy > 1:
             import torch.distributed as dist
-            self._host_staged = dist.get_backend(group) == "gloo"
+            self._host_staged = dist.is_initialized() and dist.get_backend(group) == "gloo"
         if self.slab and cfg["pres"] != 2:
             raise ValueError("slab decomposition implements pres_2 (BASELINE.json multi-GPU configs use pres_2)")
         z = moser_z(ktot, cfg["size"][2]) if case == "moser600" else None
@@ -359,10 +359,16 @@ class HotPath:
         self._transpose()                                                    # Transpose::exec_xy
         self._ok(lib.mhh_pres_fwd_y_solve_bwd_y(self.plan, self.G, self.xrecv.data_ptr(), self.xsend.data_ptr(), self.stream))
         self._transpose()                                                    # Transpose::exec_yx
-        self._ok(lib.mhh_pres_bwd_x_unpack(self.plan, self.G, self.xrecv.data_ptr(), C.byref(self.fields), self.stream))
-        if self.slim: self.halo([self.p], rows_south=0, rows_north=1)       # only p[j-1] at the south edge is read (pres_2.cxx:383-385)
-        else:         self.halo([self.p])
-        self._ok(lib.mhh_pres_output_order(self.G, 2, C.byref(self.fields), self.stream))
+        if self.slim:
+            # unpack + Pres_2::output in one kernel for everything but vt on the southernmost row, whose p[j-1] arrives with the
+            # one-row halo of p (pres_2.cxx:383-385)
+            self._ok(lib.mhh_pres_bwd_x_unpack_output(self.plan, self.G, self.xrecv.data_ptr(), C.byref(self.fields), self.stream))
+            self.halo([self.p], rows_south=0, rows_north=1)
+            self._ok(lib.mhh_pres_output_south_row(self.G, C.byref(self.fields), self.stream))
+        else:
+            self._ok(lib.mhh_pres_bwd_x_unpack(self.plan, self.G, self.xrecv.data_ptr(), C.byref(self.fields), self.stream))
+            self.halo([self.p])
+            self._ok(lib.mhh_pres_output_order(self.G, 2, C.byref(self.fields), self.stream))
 
     def _transpose(self):
         """x<->y transpose of the spectral pressure: one equal-split all-to-all (RCCL over xGMI)."""

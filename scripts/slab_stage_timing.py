@@ -38,9 +38,11 @@ res = {
  "pres_input": timeit(lambda: lib.mhh_pres_input_packed(hp.G, 2, f, 1.0, packed, st)),
  "fwd_x_pack": timeit(lambda: lib.mhh_pres_fwd_x_pack(hp.plan, hp.G, packed, hp.xsend.data_ptr(), st)),
  "fwd_y_solve_bwd_y": timeit(lambda: lib.mhh_pres_fwd_y_solve_bwd_y(hp.plan, hp.G, hp.xrecv.data_ptr(), hp.xsend.data_ptr(), st)),
- "bwd_x_unpack": timeit(lambda: lib.mhh_pres_bwd_x_unpack(hp.plan, hp.G, hp.xrecv.data_ptr(), f, st)),
+ "bwd_x_unpack_output (fused)": timeit(lambda: lib.mhh_pres_bwd_x_unpack_output(hp.plan, hp.G, hp.xrecv.data_ptr(), f, st)),
  "halo(p, 1 row north)": timeit(lambda: hp.halo([hp.p], rows_south=0, rows_north=1)),
- "pres_output": timeit(lambda: lib.mhh_pres_output_order(hp.G, 2, f, st)),
+ "pres_output south row": timeit(lambda: lib.mhh_pres_output_south_row(hp.G, f, st)),
+ "(two-kernel form) bwd_x_unpack": timeit(lambda: lib.mhh_pres_bwd_x_unpack(hp.plan, hp.G, hp.xrecv.data_ptr(), f, st)),
+ "(two-kernel form) pres_output": timeit(lambda: lib.mhh_pres_output_order(hp.G, 2, f, st)),
  "full step (no comm)": timeit(hp.step),
 }
 for k, v in res.items(): print("%-32s %8.3f ms" % (k, v))
