@@ -56,10 +56,14 @@ def test_kernel_forms_agree_at_full_size(case, shape):
         assert float(hp.evisc[hp.grid.kstart:hp.grid.kend].min()) > 0.
         del ev_march
     fused = _run_rhs(hp, hp.rhs)                                   # k-marching kernels
-    unfused = _run_rhs(hp, hp.rhs_unfused)                         # Advec::exec + Diff::exec, one cell kernel per field
+    unfused = _run_rhs(hp, hp.rhs_unfused)                         # Advec::exec + Diff::exec: the marching kernels, one operator each
     names = ["ut", "vt", "wt", "st"]
     for a, b, n in zip(fused, unfused, names):
         assert torch.equal(a, b), (case, shape, n, float((a - b).abs().max()))
+    perfield = _run_rhs(hp, hp.rhs_unfused, env={"MHH_ADVEC25_IMPL": "cell", "MHH_DIFF22_IMPL": "cell", "MHH_RHS44_IMPL": "cell"})   # one cell kernel per field
+    for a, b, n in zip(fused, perfield, names):
+        assert torch.equal(a, b), (case, shape, n, "per-field kernels")
+    del perfield
     cell = _run_rhs(hp, hp.rhs, env={"MHH_RHS25_IMPL": "cell", "MHH_RHS44_IMPL": "cell"})   # fused cell kernels
     for a, b, n in zip(fused, cell, names):
         assert torch.equal(a, b), (case, shape, n, "fused cell form")
