@@ -57,6 +57,10 @@ inline int check_grid(const mhh_grid* g)
         g->imax < 1 || g->jmax < 1 || g->kmax < 1)
     { set_error("inconsistent grid index bundle"); return MHH_EINVAL; }
     if (g->npx != 1) { set_error("only slab decomposition (npx == 1) is supported"); return MHH_EINVAL; }
+    // cell indices are 32-bit ints, as the reference's ijk (include/grid.h): refuse grids whose ghosted size does not fit,
+    // with room for the stencil offsets, instead of overflowing (2^31 cells x 8 B = 17 GB per field: possible on 288 GB)
+    if ((long long)g->ijcells * (long long)(g->kcells + 4) >= 2147483647LL || (long long)g->icells * (long long)g->jcells >= 2147483647LL)
+    { set_error("grid too large for 32-bit cell indices (icells*jcells*(kcells+4) must stay below 2^31)"); return MHH_EINVAL; }
     return MHH_OK;
 }
 

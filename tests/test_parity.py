@@ -550,6 +550,18 @@ def test_advec4_and_diff4_alone_marching_form_equals_per_field_kernels(be, dtype
                 assert same(a, b), (shape, nm, fld, cm.ulp_diff(a, b))
 
 
+def test_grid_beyond_32_bit_cell_indices_is_refused(be):
+    """Cell indices are ints like the reference's ijk: a grid whose ghosted size does not fit is an error, not an overflow."""
+    g = cm.grid_2nd(16, 12, 10, gc=(1, 1, 1))
+    G = g.host_struct()
+    G.contents.imax = G.contents.itot = 2046; G.contents.icells = 2048; G.contents.iend = 2047
+    G.contents.jmax = G.contents.jtot = 2046; G.contents.jcells = 2048; G.contents.jend = 2047
+    G.contents.ijcells = 2048*2048
+    G.contents.kmax = G.contents.ktot = 510; G.contents.kcells = 512; G.contents.kend = 511
+    rc = be.lib.mhh_boundary_cyclic(G, None, cm.EDGE_BOTH if hasattr(cm, "EDGE_BOTH") else 3, be.stream)
+    assert rc != 0 and b"32-bit" in be.lib.mhh_last_error()
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_rhs25_march_copy_forms_agree(be, dtype):
     """The three plane-copy forms of k_march.hip (16-byte LDS-DMA, 4-byte LDS-DMA, register-staged) and the cell kernel
