@@ -13,8 +13,9 @@ namespace mhh
 // first LDS read after the copy was issued -- the copy of the NEXT plane then never overlaps the compute on the current
 // ones, which is the whole point of the ring. Here the ordering is the kernels' own: a copy is issued after the barrier
 // that retires the slot's last readers, and wait_vmem() + barrier stand between the copy and the slot's first reader.
-// RAW = false is the builtin form. The fp64 kernels take RAW (2i5+smag2 -1.5 %, advec_4+diff_4 -10 % at 512x256x256);
-// the fp32 kernels, at four waves per SIMD, measured 11 % SLOWER with it (gabls1 1024x1024x256) and keep the builtin.
+// RAW = false is the builtin form (2i5+smag2 -1.5 %, advec_4+diff_4 -10 % at 512x256x256 with RAW). With the 64-bit vector
+// address of this first raw form the fp32 kernels, at four waves per SIMD, measured 11 % SLOWER (gabls1 1024x1024x256);
+// the scalar-base form below (lds_dma_sv) is the one all kernels use now, fp32 included (-1 % there).
 // (-DMHH_DMA_BUILTIN forces the builtin everywhere for A/B runs.)
 __device__ __forceinline__ unsigned lds_address(void* lds_wave_base)
 {

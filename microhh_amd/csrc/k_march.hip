@@ -182,11 +182,11 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
     };
     // LDS-DMA movers: PB bytes per lane straight into the ring slot; lanes outside the tile / the array sit out
     const int wave_e0 = tid & ~63;                                    // first piece index of this wave within a sweep
-    // SV: the copy as scalar base + per-lane byte offset + scalar LDS address (fp64 form, gfx950_prims.h): no vector ALU per piece
+    // SV: the copy as scalar base + per-lane byte offset + scalar LDS address (gfx950_prims.h): no vector ALU per piece
 #ifdef MHH_DMA_NO_SV
     constexpr bool SV = false;
 #else
-    constexpr bool SV = DMA && (MHH_RAW_DMA != 0) && (sizeof(TF) == 8);
+    constexpr bool SV = DMA && (MHH_RAW_DMA != 0);
 #endif
     const unsigned wave_lds = uniform_u32((unsigned)(wave_e0*PW*4));
     auto dma_piece = [&](const TF* plane, int word_off, TF* lds, int n)

@@ -59,11 +59,11 @@ struct TileCopy
     static constexpr int PPR = TI*EW / PW, NP = PPR*TJ, NLD = (NP + NT - 1) / NT;
     static_assert(PB == 4 || PB == 16, "piece size");
     static_assert((TI*EW) % PW == 0, "tile row must be a whole number of pieces");
-    // SV: scalar-base + lane-offset form of the raw copy (fp64 kernels, see gfx950_prims.h); -DMHH_DMA_NO_SV: the 64-bit-address form
+    // SV: scalar-base + lane-offset form of the raw copy (see gfx950_prims.h); -DMHH_DMA_NO_SV: the 64-bit-address form (fp64) / builtin (fp32)
 #ifdef MHH_DMA_NO_SV
     static constexpr bool SV = false;
 #else
-    static constexpr bool SV = (MHH_RAW_DMA != 0) && (sizeof(TF) == 8);
+    static constexpr bool SV = (MHH_RAW_DMA != 0);
 #endif
     int off[NLD]; bool ok[NLD]; int wave_e0; unsigned wave_lds;
     __device__ __forceinline__ void init(int tid, int gi0, int gj0, int icells, int jcells)
