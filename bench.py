@@ -116,6 +116,10 @@ def main():
         if world > 1:
             if args.share_gpu: dist.init_process_group("gloo")
             else:              dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        elif os.environ.get("MHH_FORCE_COMM") == "1":
+            # one rank, exchanges through RCCL anyway (to self; with --force-slab): what the collectives' call overhead costs per step
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
     else:
         if not os.environ.get("MHH_LIB"):
             sys.exit("--device cpu is a rehearsal mode: point MHH_LIB at tests/emul/libmhh_emul.so")
@@ -225,7 +229,7 @@ def main():
     hp.close()
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -79,7 +79,10 @@ class HotPath:
         # gloo, which has no device-side send/recv or all-to-all, so the MESSAGES (never the compute) pass through host
         # copies. With the nccl backend (= RCCL, the product path) the device buffers go to the collective as they are.
         self._host_staged = False
-        if self.on_gpu and npy > 1:
+        # MHH_FORCE_COMM=1 (tests): with one rank, still send the halos / transposes / maxima through torch.distributed (to
+        # self) instead of the local-copy shortcuts -- exercises the real RCCL calls on a one-GPU box
+        self._force_comm = os.environ.get("MHH_FORCE_COMM", "0") == "1"
+        if self.on_gpu and (npy > 1 or self._force_comm):
             import torch.distributed as dist
             self._host_staged = dist.is_initialized() and dist.get_backend(group) == "gloo"
         if self.slab and cfg["pres"] != 2:
@@ -238,7 +241,7 @@ class HotPath:
     def _ring(self, rs, rn, s_south, s_north, r_south, r_north, send, recv):
         """The message part of _exchange_ns: my northbound rows to the north neighbour, southbound rows to the south one."""
         import torch.distributed as dist
-        if self.npy == 1:          # both neighbours are this rank: the exchange is a local swap
+        if self.npy == 1 and not self._force_comm:          # both neighbours are this rank: the exchange is a local swap
             r_south.copy_(s_north); r_north.copy_(s_south)
         else:
             south, north = (self.rank - 1) % self.npy, (self.rank + 1) % self.npy
@@ -261,7 +264,7 @@ class HotPath:
     def _halo2d(self, t):
         """One-time periodic ghost cells of a 2-D surface array (Boundary_cyclic::exec_2d, src/boundary_cyclic.cxx:445-500)."""
         g = self.grid
-        if self.npy == 1:
+        if self.npy == 1 and not self._force_comm:
             self._ok(self.lib.mhh_boundary_cyclic_2d(self.G, t.data_ptr(), self.stream))
             return
         import torch.distributed as dist
@@ -372,7 +375,7 @@ class HotPath:
 
     def _transpose(self):
         """x<->y transpose of the spectral pressure: one equal-split all-to-all (RCCL over xGMI)."""
-        if self.npy == 1:
+        if self.npy == 1 and not self._force_comm:
             self.xrecv.copy_(self.xsend)
             return
         import torch.distributed as dist
@@ -395,7 +398,7 @@ class HotPath:
 
     # -- reductions (local max, then MAX over ranks: Master::max, src/master_parallel.cxx:233-266) --------------
     def _allmax(self, v):
-        if self.npy == 1:
+        if self.npy == 1 and not self._force_comm:
             return v
         import torch.distributed as dist
         t = self.torch.tensor([v], device=("cpu" if self._host_staged else self.device), dtype=self.torch.float64)
