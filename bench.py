@@ -109,6 +109,11 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched through torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
     on_gpu = args.device == "cuda"
+    # stdout carries exactly ONE line, the JSON: RCCL prints a version banner to stdout when a communicator is created (and
+    # gloo its connection notes), so while the job runs file descriptor 1 points at stderr; it is restored for the JSON line.
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
     if on_gpu:
         if args.share_gpu:
             local = 0
@@ -227,10 +232,12 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and on_gpu:
         out["cpu_baseline"] = cpu_baseline("drycblles" if case == "gabls1" else case)
     hp.close()
-    if rank == 0:
-        print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(stdout_fd, 1); os.close(stdout_fd)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
