@@ -223,7 +223,7 @@ def main():
     if args.workload == "drycblles512" and world == 1 and not args.unfused:
         # HBM bytes per launch of this kernel on this workload from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and
         # WRITE_SIZE in separate runs, FETCH_SIZE doubled for gfx950): profiles/r1j_kernels_pmc.md
-        out["roofline"]["traffic"] = (7.4575e6 * 2 + 4.3092e6) * 1024
+        out["roofline"]["traffic"] = 14.28e9 + 4.70e9               # FETCH_SIZE x 2 + WRITE_SIZE per launch (scripts/gpu_traffic.sh)
         out["roofline"]["traffic_source"] = "profiles/r1j_kernels_pmc.md"
     if not on_gpu:
         out["data"] = "synthetic; CPU REHEARSAL of the script (emulated kernels, gloo): not a measurement"

@@ -85,6 +85,10 @@ template<class T> __device__ __forceinline__ T uniform_load(const T* table, int 
     typedef const T __attribute__((address_space(4)))* const_ptr;
     return ((const_ptr)(table))[idx];
 }
+// Loads / stores of data touched once per kernel (the tendencies of the marching kernels): the non-temporal hint lets them
+// stream past L2 instead of evicting the planes that neighbouring tiles re-read.
+template<class T> __device__ __forceinline__ T stream_load(const T* q) { return __builtin_nontemporal_load(q); }
+template<class T> __device__ __forceinline__ void stream_store(T* q, T v) { __builtin_nontemporal_store(v, q); }
 // Wait until all of this wave's vector-memory operations (loads, stores, LDS-DMA) have completed. Inline asm on
 // purpose: the compiler may not elide or move it (MI355X_MICROARCH.md, "Compiler hazard").
 // The builtin behind it (s_waitcnt vmcnt(0), other counters untouched) tells the compiler's own wait-count bookkeeping

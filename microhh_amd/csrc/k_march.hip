@@ -126,6 +126,16 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
     const int ci = (i < g.iend) ? i : g.iend-1, cj = (j < mt.jlim) ? j : mt.jlim-1;   // clamped column for the window loads
     const int col = ci + cj*jj;
     const int ij = col;
+    // tendencies are touched once per kernel: their loads and stores carry the non-temporal hint, so that they stream past L2
+    // instead of evicting the field planes that neighbouring tiles re-read (512^3: HBM fetch 15.4 -> 14.1 GB per launch, same
+    // time; -DMHH_MARCH_NO_NT for A/B runs)
+#ifndef MHH_MARCH_NO_NT
+    auto tld = [](const TF* q) -> TF { return stream_load(q); };
+    auto tst = [](TF* q, TF v) { stream_store(q, v); };
+#else
+    auto tld = [](const TF* q) -> TF { return *q; };
+    auto tst = [](TF* q, TF v) { *q = v; };
+#endif
     const int l = (ty+3)*TI + (tx+3), le = (ty+1)*TE + (tx+EX);
     auto slot = [](int p, int r) { return (p + 12) % r; };            // 12 is a multiple of every ring depth
 
@@ -311,14 +321,14 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
         if (DSTORE && dsk >= 0 && active)
         {
             const int cd = col + dsk*kk;
-            if (DSTORE == 1) { f.ut[cd] = dsu; f.vt[cd] = dsv; }
-            if (DSTORE <= 2 && dsw_on) f.wt[cd] = dsw;
-            if (HAS_S) f.st[cd] = dss;
+            if (DSTORE == 1) { tst(f.ut + cd, dsu); tst(f.vt + cd, dsv); }
+            if (DSTORE <= 2 && dsw_on) tst(f.wt + cd, dsw);
+            if (HAS_S) tst(f.st + cd, dss);
         }
         dsk = -1;
         const TF tcu = tpu, tcv = tpv, tcw = tpw, tcs = tps;      // this level's tendencies (loaded during the previous level)
         if (TPREF && more && active) {     // the warm-up level ks = kb-1 fetches those of kb
-            const int cn = col + (k+1)*kk; tpu = f.ut[cn]; tpv = f.vt[cn]; tpw = f.wt[cn]; if (HAS_S) tps = f.st[cn]; }
+            const int cn = col + (k+1)*kk; tpu = tld(f.ut + cn); tpv = tld(f.vt + cn); tpw = tld(f.wt + cn); if (HAS_S) tps = tld(f.st + cn); }
 
         const TF* __restrict__ uk = U[slot(k, RU)] + l;  const TF* __restrict__ ukm = U[slot(k-1, RU)] + l;
         const TF* __restrict__ vk = V[slot(k, RU)] + l;  const TF* __restrict__ vkm = V[slot(k-1, RU)] + l;
@@ -390,7 +400,7 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
                 TF ue = 0, uwf = 0, vn = 0, vs = 0;
                 if constexpr (ADV) { ue = i2(uk[0], uk[1]); uwf = i2(uk[-1], uk[0]);
                                      vn = i2(vk[TI-1], vk[TI]); vs = i2(vk[-1], vk[0]); }
-                TF t = TPREF ? tcu : f.ut[c];
+                TF t = TPREF ? tcu : tld(f.ut + c);
                 if constexpr (ADV)
                 {
                     t += advec25_hor(uk, 0, TI, ue, uwf, vn, vs, dxi, dyi);
@@ -411,13 +421,13 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
                     t += hor + ver;
                 }
                 dsk = k;
-                if (DSTORE == 1) dsu = t; else f.ut[c] = t;
+                if (DSTORE == 1) dsu = t; else tst(f.ut + c, t);
             }
             {   // v
                 TF ue = 0, uwf = 0, vn = 0, vs = 0;
                 if constexpr (ADV) { ue = i2(uk[1-TI], uk[1]); uwf = i2(uk[-TI], uk[0]);
                                      vn = i2(vk[0], vk[TI]); vs = i2(vk[-TI], vk[0]); }
-                TF t = TPREF ? tcv : f.vt[c];
+                TF t = TPREF ? tcv : tld(f.vt + c);
                 if constexpr (ADV)
                 {
                     t += advec25_hor(vk, 0, TI, ue, uwf, vn, vs, dxi, dyi);
@@ -437,7 +447,7 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
                     else         ver = div_rho( Dv - cDv, rk, rk1 ) * dzi;
                     t += hor + ver;
                 }
-                if (DSTORE == 1) dsv = t; else f.vt[c] = t;
+                if (DSTORE == 1) dsv = t; else tst(f.vt + c, t);
             }
             dsw_on = (FAST || k > g.kstart);
             if (FAST || k > g.kstart)
@@ -445,7 +455,7 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
                 TF ue = 0, uwf = 0, vn = 0, vs = 0;
                 if constexpr (ADV) { ue = i2(ukm[1], uk[1]); uwf = i2(ukm[0], uk[0]);
                                      vn = i2(vkm[TI], vk[TI]); vs = i2(vkm[0], vk[0]); }
-                TF t = TPREF ? tcw : f.wt[c];
+                TF t = TPREF ? tcw : tld(f.wt + c);
                 if (HAS_S && f.threfh) { const TF th_k = uniform_load(f.threfh, k); t += f.grav/th_k * (i2(sw[2], sw[3]) - th_k); }   // src/thermo_dry.cxx:165-178
                 if constexpr (ADV)
                 {
@@ -464,11 +474,11 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
                            - es*((wk[0 ]-wk[-TI])*dyd + (vk[0 ]-vkm[0 ])*dzhi) ) * dyd
                          + div_rho( Dw - cDw, rhk, rhk1 ) * TF(2.)*dzhi;
                 }
-                if (DSTORE == 1 || DSTORE == 2) dsw = t; else f.wt[c] = t;
+                if (DSTORE == 1 || DSTORE == 2) dsw = t; else tst(f.wt + c, t);
             }
             if (HAS_S)
             {   // scalar
-                TF t = TPREF ? tcs : f.st[c];
+                TF t = TPREF ? tcs : tld(f.st + c);
                 if constexpr (ADV)
                 {
                     t += advec25_hor(sk, 0, TI, uk[1], uk[0], vk[TI], vk[0], dxi, dyi);
@@ -488,7 +498,7 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
                     else         ver = div_rho( Ds - cDs, rk, rk1 ) * dzi;
                     t += hor + ver;
                 }
-                if (DSTORE) dss = t; else f.st[c] = t;
+                if (DSTORE) dss = t; else tst(f.st + c, t);
             }
         }
         STAMP(3);
@@ -539,9 +549,9 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
     if (DSTORE && dsk >= 0 && active)
     {
         const int cd = col + dsk*kk;
-        if (DSTORE == 1) { f.ut[cd] = dsu; f.vt[cd] = dsv; }
-        if (DSTORE <= 2 && dsw_on) f.wt[cd] = dsw;
-        if (HAS_S) f.st[cd] = dss;
+        if (DSTORE == 1) { tst(f.ut + cd, dsu); tst(f.vt + cd, dsv); }
+        if (DSTORE <= 2 && dsw_on) tst(f.wt + cd, dsw);
+        if (HAS_S) tst(f.st + cd, dss);
     }
 #ifdef MHH_MARCH_STAMPS
     if ((threadIdx.x & 63) == 0) for (int n=0; n<8; ++n) atomicAdd(&g_march_stamps[n], stamp_acc[n]);

@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(64*NJ, MHH_MARCH4_OCC) rhs44_march_kernel(cons
 #endif
     constexpr bool TPREF = (MHH_MARCH4_TPREF != 0);
     TF tnu = 0, tnv = 0, tnw = 0;
-    if (TPREF && active && kb < ke) { const int c0 = col + kb*kk; tnu = f.ut[c0]; tnv = f.vt[c0]; tnw = f.wt[c0]; }
+    if (TPREF && active && kb < ke) { const int c0 = col + kb*kk; tnu = stream_load(f.ut + c0); tnv = stream_load(f.vt + c0); tnw = stream_load(f.wt + c0); }
     wait_vmem();
     __syncthreads();
 
@@ -121,9 +121,9 @@ __global__ void __launch_bounds__(64*NJ, MHH_MARCH4_OCC) rhs44_march_kernel(cons
     {
         const bool more = (k + 1 < ke);
         if (more) dma_tile(f.w, k+3, W[sw(k+3)]);
-        if (c_pending >= 0) { f.ut[c_pending] = ut_pending; f.vt[c_pending] = vt_pending; c_pending = -1; }
+        if (c_pending >= 0) { stream_store(f.ut + c_pending, ut_pending); stream_store(f.vt + c_pending, vt_pending); c_pending = -1; }
         const TF tcu = tnu, tcv = tnv, tcw = tnw;
-        if (TPREF && more && active) { const int cn = col + (k+1)*kk; tnu = f.ut[cn]; tnv = f.vt[cn]; tnw = f.wt[cn]; }
+        if (TPREF && more && active) { const int cn = col + (k+1)*kk; tnu = stream_load(f.ut + cn); tnv = stream_load(f.vt + cn); tnw = stream_load(f.wt + cn); }
         const TF nu = more ? colval(f.u, k+4) : TF(0), nv = more ? colval(f.v, k+4) : TF(0), nw = more ? colval(f.w, k+4) : TF(0);
 
         const MarchView<TF, TI> Uv{{U[su(k-2)]+l, U[su(k-1)]+l, U[su(k)]+l, U[su(k+1)]+l, nullptr}, uw};
@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(64*NJ, MHH_MARCH4_OCC) rhs44_march_kernel(cons
             const TF gw4[4] = {uniform_load(g.dzi4, k-2), uniform_load(g.dzi4, k-1), uniform_load(g.dzi4, k), uniform_load(g.dzi4, k+1)};
             if constexpr (ADV) advec4_mom_v<2>(ad, Wv, Uv, Vv, Wv, botw, top, dxi, dyi, uniform_load(g.dzhi4, k), dim3);
             if constexpr (DIF) diff4_v(df, Wv, botw, top, f.visc, g.dxidxi_t, g.dyidyi_t, gw4, uniform_load(g.dzhi4, k), dim3);
-            f.wt[c] = both(TPREF ? tcw : f.wt[c], ad, df);
+            stream_store(f.wt + c, both(TPREF ? tcw : stream_load(f.wt + c), ad, df));
         }
         if (more)
         {
@@ -153,17 +153,17 @@ __global__ void __launch_bounds__(64*NJ, MHH_MARCH4_OCC) rhs44_march_kernel(cons
             const TF gc4[4] = {uniform_load(g.dzhi4, k-1), uniform_load(g.dzhi4, k), uniform_load(g.dzhi4, k+1), uniform_load(g.dzhi4, k+2)};
             if constexpr (ADV) advec4_mom_v<0>(ad, Uv, Uv, Vv, Wv, bot, top, dxi, dyi, uniform_load(g.dzi4, k), dim3);
             if constexpr (DIF) diff4_v(df, Uv, bot, top, f.visc, g.dxidxi_d, g.dyidyi_d, gc4, uniform_load(g.dzi4, k), dim3);
-            ut_pending = both(TPREF ? tcu : f.ut[c], ad, df);
+            ut_pending = both(TPREF ? tcu : stream_load(f.ut + c), ad, df);
             if constexpr (ADV) advec4_mom_v<1>(ad, Vv, Uv, Vv, Wv, bot, top, dxi, dyi, uniform_load(g.dzi4, k), dim3);
             if constexpr (DIF) diff4_v(df, Vv, bot, top, f.visc, g.dxidxi_d, g.dyidyi_d, gc4, uniform_load(g.dzi4, k), dim3);
-            vt_pending = both(TPREF ? tcv : f.vt[c], ad, df);
+            vt_pending = both(TPREF ? tcv : stream_load(f.vt + c), ad, df);
             c_pending = c;
         }
         wait_vmem();                  // unconditional: every path back to the loop head carries a vmcnt(0) the compiler can see
         __syncthreads();
         if (more) { shift7(uw, nu); shift7(vw, nv); shift7(ww, nw); }
     }
-    if (c_pending >= 0) { f.ut[c_pending] = ut_pending; f.vt[c_pending] = vt_pending; }
+    if (c_pending >= 0) { stream_store(f.ut + c_pending, ut_pending); stream_store(f.vt + c_pending, vt_pending); }
 }
 
 #ifndef MHH_MARCH4_NJ

@@ -1,0 +1,26 @@
+#!/bin/bash
+# scripts/gpu_traffic.sh -- HBM traffic (FETCH_SIZE x 2 + WRITE_SIZE, two PMC passes) and duration of the kernels matching a
+# pattern, for the default library and every build under microhh_amd/variants/.
+set -o pipefail
+TAG=${1:-traffic}; WL=${2:-drycblles512}; PAT=${3:-rhs25_march}
+export TMPDIR=/tmp
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+for v in "" $(ls microhh_amd/variants/*.so 2>/dev/null); do
+  name=$(basename "${v:-default}" .so)
+  export MHH_LIB=${v:+$PWD/$v}
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$name/$c -- python3 bench.py --workload $WL --steps 2 --warmup 1 --no-cpu-baseline > $OUT/$name.$c.json 2> $OUT/$name.$c.err || { echo "$name $c failed"; tail -2 $OUT/$name.$c.err; }
+  done
+  python3 - $OUT/$name "$PAT" "$name" <<'PY'
+import csv, glob, sys
+tot = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    vals = []
+    for f in glob.glob(sys.argv[1] + "/" + c + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if sys.argv[2] in r["Kernel_Name"] and r["Counter_Name"] == c: vals.append(float(r["Counter_Value"]))
+    tot[c] = sum(vals)/max(1, len(vals))
+print("%-24s fetch %.2f GB  write %.2f GB  total %.2f GB" % (sys.argv[3], tot["FETCH_SIZE"]*2*1024/1e9, tot["WRITE_SIZE"]*1024/1e9, (tot["FETCH_SIZE"]*2 + tot["WRITE_SIZE"])*1024/1e9))
+PY
+done

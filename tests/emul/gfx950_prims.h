@@ -15,6 +15,8 @@ template<bool RAW = false> inline void lds_dma4(const void* gsrc, void* lds_wave
     std::memcpy(static_cast<char*>(lds_wave_base) + lane*4, gsrc, 4);
 }
 inline void wait_vmem() {}
+template<class T> inline T stream_load(const T* q) { return *q; }
+template<class T> inline void stream_store(T* q, T v) { *q = v; }
 #define MHH_RAW_DMA 0
 inline unsigned lds_address(void*) { return 0; }
 inline unsigned uniform_u32(unsigned v) { return v; }
