@@ -411,6 +411,7 @@ class Pres
         virtual ~Pres() { clear_device(); }
         static std::shared_ptr<Pres> factory(Grid<TF>& g, Fields<TF>& f, const std::string& swpres)
         {
+            if (swpres == "0") return std::make_shared<Pres>(g, f, 0);     // Pres_disabled (src/pres_disabled.cxx): every member does nothing
             if (swpres == "2") return std::make_shared<Pres>(g, f, 2);
             if (swpres == "4") return std::make_shared<Pres>(g, f, 4);
             throw std::runtime_error("\"" + swpres + "\" is an illegal value for swpres");
@@ -422,6 +423,7 @@ class Pres
         void prepare_device()
         {
             clear_device();
+            if (order == 0) return;
             auto& gd = grid.get_grid_data();
             mhh_grid gh = grid.abi(true);
             mhh_check(mhh_pres_plan_create(&gh, order, gd.dz.data(), gd.dzhi.data(), gd.dzi4.data(), gd.dzhi4.data(), fields.rhoref.data(), fields.rhorefh.data(), &plan));
@@ -429,12 +431,14 @@ class Pres
         void clear_device() { if (plan) { mhh_pres_plan_destroy(plan); plan = nullptr; } }
         void exec(double dt, Stats&, void* stream = nullptr)
         {
+            if (order == 0) return;
             if (!plan) throw std::runtime_error("Pres::exec before prepare_device");
             mhh_grid g = grid.abi(); mhh_fields f = abi_fields(fields);
             mhh_check(mhh_pres_exec(plan, &g, &f, dt, stream));
         }
         TF check_divergence(void* stream = nullptr)
         {
+            if (order == 0) return TF(0);                          // src/pres_disabled.cxx: check_divergence returns 0
             mhh_grid g = grid.abi(); mhh_fields f = abi_fields(fields); double d = 0;
             mhh_check(mhh_pres_check_divergence(&g, order, &f, work, &d, stream));
             return static_cast<TF>(d);

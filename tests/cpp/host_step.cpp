@@ -98,6 +98,10 @@ int main(int argc, char** argv)
         bool threw = false;
         try { Advec<TF>::factory(grid, fields, "2i7"); } catch (const std::runtime_error&) { threw = true; }
         if (!threw) { std::fprintf(stderr, "factory did not throw\n"); return 4; }
+        // the disabled operators (swadvec / swdiff / swpres = "0") exist and do nothing
+        auto pres0 = Pres<TF>::factory(grid, fields, "0");
+        pres0->prepare_device(); pres0->exec(dt, stats);
+        if (pres0->check_divergence() != TF(0)) { std::fprintf(stderr, "Pres_disabled::check_divergence\n"); return 6; }
         pres->clear_device();
         std::printf("host_step ok cfl=%.17g dn=%.17g div=%.17g\n", cfl, dnum, div);
     }
