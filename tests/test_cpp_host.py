@@ -57,7 +57,7 @@ def test_cpp_host_substep_matches_oracle(mode):
     O.orc_smag2_evisc(G, sm, ptr(ev), ptr(n2), ptr(c.dbdz), ptr(c.z0m), dbl(0.23), dbl(1./3.))
     assert cfl == O.orc_advec_cfl(G, cm.ADVEC_2I5, ptr(c.u), ptr(c.v), ptr(c.w), dbl(dt))
     it = g.interior
-    assert cm.ulp_diff(got["evisc"][it], ev[it]) <= 4
+    assert cm.ulp_diff(got["evisc"][it], ev[it]) <= 8
     ut, vt, wt, tht = c.ut.copy(), c.vt.copy(), c.wt.copy(), c.st[0].copy()
     evg = got["evisc"]          # continue from the device's evisc so that the stencil stages can be compared bit for bit
     a = (ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.rhoref), ptr(c.rhorefh))

