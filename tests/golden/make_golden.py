@@ -21,9 +21,17 @@ GRID2 = (12, 10, 8, 3, 3, 1)
 GRID4 = (12, 10, 8)
 
 
-def cases():
+def cases(z2=None, z4=None):
+    """The two input cases. The stretched grids come from tanh / log (moser_z), whose last bits depend on the host's numpy SIMD
+    dispatch: the fixture stores the two z profiles it was made with (z2, z4) and the tests rebuild the grids from those,
+    so that the vectors do not depend on the machine the tests run on. Everything else is RNG + exact arithmetic."""
+    from microhh_amd.grid import Grid
     g2 = cm.grid_2nd(*GRID2[:3], gc=GRID2[3:])
     g4 = cm.grid_4th(*GRID4)
+    if z2 is not None:
+        g2 = Grid(GRID2[0], GRID2[1], GRID2[2], g2.xsize, g2.ysize, g2.zsize, order=2, igc=GRID2[3], jgc=GRID2[4], kgc=GRID2[5], z=np.asarray(z2, dtype=np.float64))
+    if z4 is not None:
+        g4 = Grid(GRID4[0], GRID4[1], GRID4[2], g4.xsize, g4.ysize, g4.zsize, order=4, z=np.asarray(z4, dtype=np.float64))
     return g2, cm.Case(g2, seed=SEED), g4, cm.Case(g4, seed=SEED)
 
 
@@ -68,6 +76,7 @@ def main():
     out["smag_dnmul"] = np.array(R.ref_smag2_dnmul(G, ptr(c.evisc), dbl(1./3.)))
     # input fingerprint so that a drift of the input recipe is detected rather than misread as a kernel error
     out["fingerprint"] = np.array([c2.u.sum(), c2.rhorefh.sum(), c4.w.sum(), c2.evisc.sum()])
+    out["z2"] = g2.z[g2.kstart:g2.kend].astype(np.float64); out["z4"] = g4.z[g4.kstart:g4.kend].astype(np.float64)
     np.savez_compressed(os.path.join(HERE, "ref_vectors.npz"), **out)
     print("wrote %d arrays" % len(out))
 

@@ -19,13 +19,13 @@ GOLD = np.load(os.path.join(cm.ROOT, "tests", "golden", "ref_vectors.npz"))
 
 
 def test_input_recipe_unchanged():
-    g2, c2, g4, c4 = mg.cases()
+    g2, c2, g4, c4 = mg.cases(GOLD["z2"], GOLD["z4"])
     assert np.array_equal(GOLD["fingerprint"], np.array([c2.u.sum(), c2.rhorefh.sum(), c4.w.sum(), c2.evisc.sum()]))
 
 
 def test_oracle_reproduces_reference_vectors():
     O = cm.oracle()
-    g2, c2, g4, c4 = mg.cases()
+    g2, c2, g4, c4 = mg.cases(GOLD["z2"], GOLD["z4"])
     for scheme, g, c in ((2, g2, c2), (25, g2, c2), (24, g2, c2), (262, g2, c2), (253, g2, c2), (4, g4, c4), (41, g4, c4)):
         G = g.host_struct()
         for fn, tn in ((O.orc_advec_u, "ut"), (O.orc_advec_v, "vt"), (O.orc_advec_w, "wt")):
@@ -60,7 +60,7 @@ def test_oracle_reproduces_reference_vectors():
 @pytest.mark.parametrize("name", [pytest.param("emul"), pytest.param("hip", marks=pytest.mark.gpu)])
 def test_hip_path_reproduces_reference_vectors(name):
     be = B.get(name)
-    g2, c2, g4, c4 = mg.cases()
+    g2, c2, g4, c4 = mg.cases(GOLD["z2"], GOLD["z4"])
     for scheme, g, c in ((2, g2, c2), (25, g2, c2), (24, g2, c2), (262, g2, c2), (253, g2, c2), (4, g4, c4), (41, g4, c4)):
         d = B.DevCase(be, c)
         for fn, tn in ((be.lib.mhh_advec_u, "ut"), (be.lib.mhh_advec_v, "vt"), (be.lib.mhh_advec_w, "wt")):
