@@ -185,6 +185,8 @@ def main():
             if on_gpu:
                 torch.cuda.synchronize()
     barrier()
+    if on_gpu and (world > 1 or os.environ.get("MHH_FORCE_COMM") == "1") and not args.share_gpu:
+        hp.comm_timing = []                  # device-event pairs around every exchange of the timed steps
     t0 = time.perf_counter()
     for n in range(args.steps):
         one_step(events[n])
@@ -227,6 +229,12 @@ def main():
         out["roofline"]["traffic_source"] = "profiles/r1j_kernels_pmc.md"
     if not on_gpu:
         out["data"] = "synthetic; CPU REHEARSAL of the script (emulated kernels, gloo): not a measurement"
+    if hp.comm_timing:
+        # where the time of an N > 1 step goes on this rank: stream time inside the exchanges (the launch of the collective until
+        # its result is usable by the next kernel), per step; the rest of ms_per_step is kernels
+        tags = sorted({t for t, _, _ in hp.comm_timing})
+        out["comm"] = {t + "_ms_per_step": sum(a.elapsed_time(b) for tt, a, b in hp.comm_timing if tt == t) / args.steps for t in tags}
+        out["comm"]["exchanges_per_step"] = len(hp.comm_timing) / args.steps
     if on_gpu and args.share_gpu:
         out["data"] = "synthetic; REHEARSAL of the N > 1 path with all ranks on one GPU (gloo, host-staged messages): not a measurement"
     if rank == 0 and world == 1 and not args.no_cpu_baseline and on_gpu:

@@ -82,6 +82,8 @@ class HotPath:
         # MHH_FORCE_COMM=1 (tests): with one rank, still send the halos / transposes / maxima through torch.distributed (to
         # self) instead of the local-copy shortcuts -- exercises the real RCCL calls on a one-GPU box
         self._force_comm = os.environ.get("MHH_FORCE_COMM", "0") == "1"
+        # bench.py: device-event pairs around every exchange (tag, start, end) while comm_timing is a list
+        self.comm_timing = None
         if self.on_gpu and (npy > 1 or self._force_comm):
             import torch.distributed as dist
             self._host_staged = dist.is_initialized() and dist.get_backend(group) == "gloo"
@@ -238,8 +240,29 @@ class HotPath:
         self._ring(rs, rn, s_south, s_north, r_south, r_north, send, recv)
         self._ok(self.lib.mhh_halo_unpack_rows(self.G, arr, nf, rs, rn, recv.data_ptr(), recv.data_ptr() + off_s, self.stream))
 
+    def _timed(self, tag):
+        """Context manager: records a pair of events on the current stream around an exchange when comm_timing is on."""
+        hp = self
+
+        class _T:
+            def __enter__(self_):
+                self_.on = hp.comm_timing is not None and hp.on_gpu
+                if self_.on:
+                    self_.a = hp.torch.cuda.Event(enable_timing=True); self_.b = hp.torch.cuda.Event(enable_timing=True)
+                    self_.a.record()
+
+            def __exit__(self_, *exc):
+                if self_.on:
+                    self_.b.record(); hp.comm_timing.append((tag, self_.a, self_.b))
+                return False
+        return _T()
+
     def _ring(self, rs, rn, s_south, s_north, r_south, r_north, send, recv):
         """The message part of _exchange_ns: my northbound rows to the north neighbour, southbound rows to the south one."""
+        with self._timed("halo"):
+            self._ring_impl(rs, rn, s_south, s_north, r_south, r_north, send, recv)
+
+    def _ring_impl(self, rs, rn, s_south, s_north, r_south, r_north, send, recv):
         import torch.distributed as dist
         if self.npy == 1 and not self._force_comm:          # both neighbours are this rank: the exchange is a local swap
             r_south.copy_(s_north); r_north.copy_(s_south)
@@ -384,7 +407,8 @@ class HotPath:
             dist.all_to_all_single(hr, hs, group=self.group)
             self.xrecv.copy_(hr)
             return
-        dist.all_to_all_single(self.xrecv, self.xsend, group=self.group)
+        with self._timed("transpose"):
+            dist.all_to_all_single(self.xrecv, self.xsend, group=self.group)
 
     def step(self):
         """One full RHS + pressure evaluation (the BASELINE metric's unit of work)."""
