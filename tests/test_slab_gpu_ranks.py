@@ -123,3 +123,20 @@ def test_slab_code_path_through_real_rccl_on_one_rank(overlap):
             scale = np.abs(ref[key]).max()
             assert np.abs(got[key] - ref[key]).max() <= 1e-10 * scale, (key, np.abs(got[key] - ref[key]).max() / scale)
         assert float(got["cfl"]) == float(ref["cfl"])
+
+
+def test_bench_line_under_rccl_is_one_json_line_with_comm_times():
+    """bench.py with its exchanges through real RCCL (one rank, MHH_FORCE_COMM=1, --force-slab): RCCL's banner must not reach
+    stdout (exactly one line, the JSON), and the line carries the per-exchange stream times of an N > 1 run."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MHH_FORCE_COMM="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29950 + os.getpid() % 40))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "rehearsal", "--force-slab", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, env=env, cwd=root, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["decomposition"].endswith("npy=1")
+    assert d["comm"]["exchanges_per_step"] == 5 and d["comm"]["halo_ms_per_step"] > 0 and d["comm"]["transpose_ms_per_step"] > 0
