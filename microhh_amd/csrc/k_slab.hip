@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(256) xbuf_y_kernel(C2<TF>* __restrict__ specy,
 //   * the pivots w2 and the eliminated upper diagonal w3 depend on the grid and (kx, ky) only: computed ONCE at plan
 //     creation (tdma_slab_factor_kernel, the reference's recurrence) and kept, 2 x nxb*jtot*kmax values;
 //   * one thread per (ky, re|im) component -- twice the parallelism, lanes still read consecutive 8-byte words;
-//   * the right-hand side and pivots of the next 8 levels are loaded while the 8 current levels run through the
+//   * the right-hand side and pivots of the next 16 levels are loaded while the 16 current levels run through the
 //     recurrence (only a multiply-subtract and the division by the pivot are left on the dependent chain).
 template<class TF>
 __global__ void __launch_bounds__(64) tdma_slab_factor_kernel(TF* __restrict__ W2, TF* __restrict__ W3,
@@ -319,7 +319,10 @@ __global__ void __launch_bounds__(128) tdma_slab_kernel(TF* __restrict__ p, cons
                                                         const TF* __restrict__ a, const TF* __restrict__ dz,
                                                         int nxh, int nxb, int kx0, int jtot, int kmax)
 {
-    constexpr int U = 8;
+#ifndef MHH_SLAB_U
+#define MHH_SLAB_U 16          // levels in flight per thread (512^3 / 8: y-stage 0.44 ms with 8, 0.41 with 16, 0.40 with 32)
+#endif
+    constexpr int U = MHH_SLAB_U;
     const int t = blockIdx.x*128 + threadIdx.x;           // 0 .. 2*jtot-1
     const int ky = t >> 1, comp = t & 1, kxl = blockIdx.y;
     const int kx = kx0 + kxl;                              // swapped indices: this rank owns a block of x modes, all y modes
