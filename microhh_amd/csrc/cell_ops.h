@@ -132,6 +132,41 @@ MHH_HD TF advec25_hor(const TF* __restrict__ f, int c, int jj, TF ue, TF uw, TF 
         - ( vn * i6(gm2, gm1, f0, gp1, gp2, gp3) - vs * i6(gm3, gm2, gm1, f0, gp1, gp2) ) * dyi
         + ( tabs(vn) * i5(gm2, gm1, f0, gp1, gp2, gp3) - tabs(vs) * i5(gm3, gm2, gm1, f0, gp1, gp2) ) * dyi;
 }
+// the same with the cell's own value handed over (the marching kernel holds it in a register; f points at the cell in an
+// LDS plane of row pitch jj). ue/uw/vn/vs may be SUMS a+b of the two velocities a face averages, with dxi/dyi halved by the
+// caller: scaling by 2 commutes with every rounding of the expression (no overflow; exact unless a velocity sum is subnormal),
+// so 0.5*(a+b) * I * dxi and (a+b) * I * (0.5*dxi) are the same bits -- one multiplication per face less.
+template<class TF>
+MHH_HD TF advec25_hor_f0(const TF* __restrict__ f, TF f0, int jj, TF ue, TF uw, TF vn, TF vs, TF dxi, TF dyi)
+{
+    const TF fm3 = f[-3], fm2 = f[-2], fm1 = f[-1], fp1 = f[1], fp2 = f[2], fp3 = f[3];
+    const TF gm3 = f[-3*jj], gm2 = f[-2*jj], gm1 = f[-jj], gp1 = f[jj], gp2 = f[2*jj], gp3 = f[3*jj];
+    return
+        - ( ue * i6(fm2, fm1, f0, fp1, fp2, fp3) - uw * i6(fm3, fm2, fm1, f0, fp1, fp2) ) * dxi
+        + ( tabs(ue) * i5(fm2, fm1, f0, fp1, fp2, fp3) - tabs(uw) * i5(fm3, fm2, fm1, f0, fp1, fp2) ) * dxi
+        - ( vn * i6(gm2, gm1, f0, gp1, gp2, gp3) - vs * i6(gm3, gm2, gm1, f0, gp1, gp2) ) * dyi
+        + ( tabs(vn) * i5(gm2, gm1, f0, gp1, gp2, gp3) - tabs(vs) * i5(gm3, gm2, gm1, f0, gp1, gp2) ) * dyi;
+}
+
+// x / d for a divisor known in advance, with r = RN(1/d) from an IEEE division on the host: the correctly rounded quotient in
+// five multiply-adds instead of the ~14 issue slots of a full fp64 division (v_rcp_f64, v_div_scale/fmas/fixup).
+// q0 = RN(x r) is within 1.5 ulp of x/d; one residual correction makes it a faithful rounding (the residual is exact or
+// rounded by < 2^-53 of itself, the correction term carries the 2^-53 relative error of r: together < 2^-51 ulp); from a
+// faithful quotient a second correction with the exact residual RN(x - d q) gives RN(x/d) (Markstein's theorem; it needs
+// r = RN(1/d) and a significand of d that is not all ones -- the host checks that, known_divisor_ok). Exact for x = 0 and for
+// every x whose residual does not underflow (|x| > 2^-960 in fp64): eddy viscosities are never that small.
+MHH_HD double tfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+MHH_HD float  tfma(float a, float b, float c)    { return __builtin_fmaf(a, b, c); }
+template<class TF>
+MHH_HD TF div_known(TF x, TF d, TF r)
+{
+    TF q = x * r;
+    TF e = tfma(-d, q, x);
+    q = tfma(e, r, q);
+    e = tfma(-d, q, x);
+    return tfma(e, r, q);
+}
+
 // vertical increment (:204-299 etc.) for face orders ot (top) / ob (bottom)
 template<class TF>
 MHH_HD TF advec25_ver(const TF* __restrict__ f, int c, int kk, int ot, int ob, TF wt, TF wb, TF rt, TF rb, TF rc, TF dz)

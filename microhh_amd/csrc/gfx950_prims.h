@@ -75,6 +75,35 @@ template<int PB> __device__ __forceinline__ void lds_dma_sv(const void* uniform_
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
                      : "=&s"(m0_saved) : "v"(lane_byte_offset), "s"(uniform_base), "s"(lds_wave_address) : "memory");
 }
+// The same with the LDS address as the sum of two scalars, added inside the statement: `lds_wave_base` (this wave's lane-0
+// address in the kernel's LDS array) + `lds_offset` (the destination tile, usually a compile-time constant, which then costs
+// one s_mov and no register across the loop). Written as C the sum is loop-invariant, gets hoisted for every (tile, piece)
+// pair and the ~20 sums are spilled to vector-register lanes and read back with v_readlane every level.
+template<int PB> __device__ __forceinline__ void lds_dma_sv2(const void* uniform_base, unsigned lane_byte_offset, unsigned lds_wave_base, unsigned lds_offset)
+{
+    unsigned m0_saved;
+    // wave-uniform by contract; what the compiler nevertheless holds in vector registers is moved (a no-op otherwise)
+    lds_offset = __builtin_amdgcn_readfirstlane(lds_offset);
+    const unsigned long long ub = (unsigned long long)uniform_base;
+    // (the builtin returns int: without the casts a low word with bit 31 set sign-extends over the high word)
+    uniform_base = (const void*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(ub >> 32)) << 32) |
+                                 (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)ub));
+    if constexpr (PB == 16)
+        asm volatile("s_mov_b32 %0, m0\n\ts_add_u32 m0, %3, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(m0_saved) : "v"(lane_byte_offset), "s"(uniform_base), "s"(lds_wave_base), "s"(lds_offset) : "memory", "scc");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_add_u32 m0, %3, %4\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(m0_saved) : "v"(lane_byte_offset), "s"(uniform_base), "s"(lds_wave_base), "s"(lds_offset) : "memory", "scc");
+}
+// Pin a wave-uniform value in scalar registers of its own. Kernel arguments arrive by merged s_load_dwordx8/x16, and the
+// register allocator keeps, spills and restores such a tuple as ONE value: to use one pointer of a spilled argument struct
+// it restores all sixteen dwords, each with a v_readlane_b32 -- a vector-ALU instruction. A value passed through here is a
+// separate live range (1-2 registers), and the tuple dies at the top of the kernel.
+#ifndef MHH_NO_PIN
+template<class T> __device__ __forceinline__ T sgpr(T x) { asm volatile("" : "+s"(x)); return x; }
+#else
+template<class T> __device__ __forceinline__ T sgpr(T x) { return x; }
+#endif
 // Load of a wave-uniform element of a read-only table (per-level metrics, base-state profiles) through the constant
 // address space, i.e. as an s_load on the scalar cache, tracked by lgkmcnt. A plain load of such an element inside a loop
 // that also stores is emitted as a VECTOR load (the compiler cannot prove the table is not clobbered), and its
@@ -89,6 +118,48 @@ template<class T> __device__ __forceinline__ T uniform_load(const T* table, int 
 // stream past L2 instead of evicting the planes that neighbouring tiles re-read.
 template<class T> __device__ __forceinline__ T stream_load(const T* q) { return __builtin_nontemporal_load(q); }
 template<class T> __device__ __forceinline__ void stream_store(T* q, T v) { __builtin_nontemporal_store(v, q); }
+// Global loads / stores through a wave-uniform base pointer plus a per-lane 32-bit byte offset: the saddr + voffset form of
+// global_load / global_store, with no 64-bit vector address arithmetic. The explicit global address space matters: a pointer
+// that went through sgpr() is opaque to the compiler's address-space inference and would be accessed with flat_* instructions.
+#ifndef MHH_GLOAD_PLAIN
+template<class T> __device__ __forceinline__ const T __attribute__((address_space(1)))* global_at(const T* uniform_base, unsigned lane_byte_offset)
+{
+    typedef const char __attribute__((address_space(1)))* gcp;
+    typedef const T __attribute__((address_space(1)))* gtp;
+    return (gtp)((gcp)uniform_base + lane_byte_offset);
+}
+#else
+template<class T> __device__ __forceinline__ const T* global_at(const T* uniform_base, unsigned lane_byte_offset)
+{
+    return reinterpret_cast<const T*>(reinterpret_cast<const char*>(uniform_base) + lane_byte_offset);
+}
+#endif
+template<class T> __device__ __forceinline__ T gload(const T* uniform_base, unsigned lane_byte_offset) { return *global_at(uniform_base, lane_byte_offset); }
+template<class T> __device__ __forceinline__ T gload_stream(const T* uniform_base, unsigned lane_byte_offset) { return __builtin_nontemporal_load(global_at(uniform_base, lane_byte_offset)); }
+template<class T> __device__ __forceinline__ void gstore(T* uniform_base, unsigned lane_byte_offset, T v)
+{
+#ifndef MHH_GLOAD_PLAIN
+    typedef T __attribute__((address_space(1)))* gtp; *(gtp)global_at(uniform_base, lane_byte_offset) = v;
+#else
+    *const_cast<T*>(global_at(uniform_base, lane_byte_offset)) = v;
+#endif
+}
+template<class T> __device__ __forceinline__ void gstore_stream(T* uniform_base, unsigned lane_byte_offset, T v)
+{
+#ifndef MHH_GLOAD_PLAIN
+    typedef T __attribute__((address_space(1)))* gtp; __builtin_nontemporal_store(v, (gtp)global_at(uniform_base, lane_byte_offset));
+#else
+    __builtin_nontemporal_store(v, const_cast<T*>(global_at(uniform_base, lane_byte_offset)));
+#endif
+}
+// Opaque re-definition of a per-lane value (no instruction): what is computed from it cannot be hoisted above this point.
+__device__ __forceinline__ void keep_vgpr(unsigned& x) { asm volatile("" : "+v"(x)); }
+// No instruction is scheduled across this point (bounds the live ranges the instruction scheduler creates by hoisting loads).
+#ifndef MHH_NO_SCHED_FENCE
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+#else
+__device__ __forceinline__ void sched_fence() {}
+#endif
 // Wait until all of this wave's vector-memory operations (loads, stores, LDS-DMA) have completed. Inline asm on
 // purpose: the compiler may not elide or move it (MI355X_MICROARCH.md, "Compiler hazard").
 // The builtin behind it (s_waitcnt vmcnt(0), other counters untouched) tells the compiler's own wait-count bookkeeping

@@ -4,19 +4,27 @@
 // Why this shape (numbers: profiles/r1b_sweep_xcd_tiling.md): the one-thread-per-cell version issues ~180 vector
 // loads per cell through the 64 B/clk L1 and is bound by that pipe, not by HBM or VALU. Here a 64 x NJ block of
 // threads owns a column tile and walks up in k:
-//   * the plane being updated and its two neighbours live in LDS with their halos (u, v, w: +-3; evisc: +-1),
-//     loaded once per block (x1.9..2.7 halo amplification instead of x20 re-reads), read back with ds_read_b64;
-//   * each thread keeps the 7-deep k-window of its own column of u, v, w, s in registers;
+//   * the plane being updated lives in LDS with its halo (u, v, w, s: +-3; evisc: +-1, three levels), loaded once per
+//     block by LDS-DMA (16-byte pieces on aligned rows, 4-byte pieces on any other layout) into a spare ring slot while
+//     the current level is being computed: one barrier per level;
+//   * each thread keeps the 6-level k-window (k-2 .. k+3) of its own column of u, v, w, s in registers -- the cell's own
+//     values and its k-1 / k+1 neighbours come from there, not from LDS; u(i+1) and v(j+1) of level k-1, which the w
+//     equation needs, are carried over from the previous level, so that the u, v rings hold the current plane only;
 //   * vertical face fluxes (advective centred/upwind parts and the Smagorinsky stress) are computed once, on the
 //     top face, and carried to the next level as its bottom face -- identical operands, identical rounding, so
 //     the result is still bit-identical to the reference CPU path (src/advec_2i5.cxx, src/diff_smag2.cxx);
-//   * the next plane travels global -> LDS by LDS-DMA (16-byte pieces on aligned rows, 4-byte pieces on any other layout)
-//     into a spare ring slot while the current level is being computed: one barrier per level; a register-staged copy
-//     form (two barriers) remains selectable for A/B runs (MHH_MARCH_DMA=0);
-//   * fp64: the level body exists in four instantiations (interior level or not, base-state density exactly 1 or not),
-//     so that on the hot path the face orders, wall predicates and density factors are compile-time constants.
+//   * interior levels run in groups of six with the register windows ROTATED at compile time (the level body is
+//     instantiated for the six rotations): no register copies to shift four 6-level windows and twelve carried faces
+//     per level (they were ~140 of the ~880 vector instructions per cell of the shifted form);
+//   * the level body exists per (interior level or not, base-state density exactly 1 or not), so that on the hot path
+//     the face orders, wall predicates and density factors are compile-time constants.
+// Exact strength reductions (all checked bit for bit against the oracle, tests/test_parity.py):
+//   * 0.5*(a+b) of an advecting velocity is folded into the metric (advec25_hor_f0, cell_ops.h);
+//   * X * 2 * m is X * (2m); 0.5*s/tPr is s/(2 tPr);
+//   * the division by the (uniform) turbulent Prandtl number is div_known (cell_ops.h): correctly rounded in 5 FMAs.
 // Accumulation order per tendency is the reference's: t += advec_horizontal; t += advec_vertical; t += diffusion.
-// Measurements and the experiments that did not pay: profiles/r1c_march_kernel_pmc.md, profiles/r1e_kernels_pmc.md.
+// Measurements and the experiments that did not pay: profiles/r1c_march_kernel_pmc.md, profiles/r1e_kernels_pmc.md,
+// profiles/r2*_march*.md.
 #include <cstdint>
 #include <cstdlib>
 #include <type_traits>
@@ -26,26 +34,20 @@
 
 using namespace mhh;
 
-// Diagnostic build only (-DMHH_MARCH_STAMPS): per-segment cycle sums of the marching loop, never compiled into the product.
-#ifdef MHH_MARCH_STAMPS
-__device__ unsigned long long g_march_stamps[8];
-#define STAMP(n) do { const unsigned long long t_ = clock64(); stamp_acc[n] += t_ - stamp_t; stamp_t = t_; } while (0)
-#else
-#define STAMP(n)
-#endif
-
 namespace
 {
-template<class TF> __device__ __forceinline__ TF win_cen(const TF (&w)[7], int order)     // window index 3 = level k; face k+1/2
+// 6-level register window of a column: logical index n holds level k-2+n; with rotation R it lives in w[(n+R) % 6]
+template<int R, int N, class TF> __device__ __forceinline__ TF wv(const TF (&w)[6]) { return w[(N + R) % 6]; }
+template<int R, class TF> __device__ __forceinline__ TF win_cen(const TF (&w)[6], int order)     // face k+1/2
 {
-    if (order == 2) return i2(w[3], w[4]);
-    if (order == 4) return i4ws(w[2], w[3], w[4], w[5]);
-    return i6(w[1], w[2], w[3], w[4], w[5], w[6]);
+    if (order == 2) return i2(wv<R,2>(w), wv<R,3>(w));
+    if (order == 4) return i4ws(wv<R,1>(w), wv<R,2>(w), wv<R,3>(w), wv<R,4>(w));
+    return i6(wv<R,0>(w), wv<R,1>(w), wv<R,2>(w), wv<R,3>(w), wv<R,4>(w), wv<R,5>(w));
 }
-template<class TF> __device__ __forceinline__ TF win_upw(const TF (&w)[7], int order)
+template<int R, class TF> __device__ __forceinline__ TF win_upw(const TF (&w)[6], int order)
 {
-    if (order == 4) return i3ws(w[2], w[3], w[4], w[5]);
-    return i5(w[1], w[2], w[3], w[4], w[5], w[6]);
+    if (order == 4) return i3ws(wv<R,1>(w), wv<R,2>(w), wv<R,3>(w), wv<R,4>(w));
+    return i5(wv<R,0>(w), wv<R,1>(w), wv<R,2>(w), wv<R,3>(w), wv<R,4>(w), wv<R,5>(w));
 }
 // vertical advective increment from the face products T = rt*w_t*I_t, B = rb*w_b*I_b, Gt = rt*|w_t|*D_t, Gb likewise
 // x / rc with the wave-uniform shortcut for rc == 1 (Boussinesq base state): x / 1 is x, bit for bit, and an
@@ -64,40 +66,61 @@ template<class TF> __device__ __forceinline__ TF vert_combine(int ot, int ob, TF
     if (ub)       return cen - div_rho( Gb, rc, one ) * dz;
     return cen;
 }
-template<class TF> __device__ __forceinline__ void shift(TF (&w)[7], TF nw)
+template<class TF> __device__ __forceinline__ void shift6(TF (&w)[6], TF nw)
 {
-    w[0] = w[1]; w[1] = w[2]; w[2] = w[3]; w[3] = w[4]; w[4] = w[5]; w[5] = w[6]; w[6] = nw;
+    w[0] = w[1]; w[1] = w[2]; w[2] = w[3]; w[3] = w[4]; w[4] = w[5]; w[5] = nw;
 }
 
 template<class TF> struct MarchFields
 {
+    // hot: every level of the interior loop uses these
     const TF* __restrict__ u; const TF* __restrict__ v; const TF* __restrict__ w; const TF* __restrict__ s; const TF* __restrict__ ev;
     TF* __restrict__ ut; TF* __restrict__ vt; TF* __restrict__ wt; TF* __restrict__ st;
+    TF dxih, dyih;                               // 0.5 * TF(1.)/dx : advection of u, v, w (the 1/2 of the advecting-velocity mean folded in)
+    TF dxi, dyi;                                 // TF(1.)/dx       : advection of the scalar
+    TF dxd, dyd, dxd2, dyd2;                     // TF(1./dx) and twice that: diffusion
+    TF dxidxi, dyidyi;                           // TF(1./(dx*dx)): diffusion of the scalar
+    TF visc, svisc;
+    TF tPr2, rtPr2;                              // 2 tPr and RN(1 / (2 tPr)): 0.5*(a+b)/tPr is div_known(a+b, tPr2, rtPr2)
+    // cold: walls, surface model, anelastic base state, folded buoyancy
     const TF* __restrict__ rhoref; const TF* __restrict__ rhorefh;
     const TF* __restrict__ ufb; const TF* __restrict__ uft; const TF* __restrict__ vfb; const TF* __restrict__ vft;
     const TF* __restrict__ sfb; const TF* __restrict__ sft;
-    TF visc, svisc, tPr; int sm;
     const TF* __restrict__ threfh; TF grav;      // folded dry buoyancy of the scalar (threfh == nullptr: off)
+    int sm;
 };
 
+// x * 2^E for a wave-uniform, normal, non-zero x (a grid metric): an integer add on the exponent field, which stays on the
+// scalar ALU -- gfx950 has no scalar fp64 multiply, and a vector one would park the uniform result in vector registers.
+template<int E> __device__ __forceinline__ double scale2(double x)
+{
+    return __builtin_bit_cast(double, __builtin_bit_cast(long long, x) + (long long)E * (1LL << 52));
+}
+template<int E> __device__ __forceinline__ float scale2(float x)
+{
+    return __builtin_bit_cast(float, __builtin_bit_cast(int, x) + E * (1 << 23));
+}
+
+#ifndef MHH_MARCH_NJ
+#define MHH_MARCH_NJ 4
+#endif
 #ifndef MHH_MARCH_OCC
-#define MHH_MARCH_OCC 2           // fp64: 213-237 VGPRs, 74.6 KB LDS -> two blocks per CU
+#define MHH_MARCH_OCC 2           // blocks per CU the fp64 register budget is set for
 #endif
 #ifndef MHH_MARCH_OCC_F32
 #define MHH_MARCH_OCC_F32 4       // fp32: half the registers and LDS -> four waves per SIMD (gabls1 1024x1024x256: 8.5 -> 7.9 ms)
 #endif
-// DMA = true : planes travel global -> LDS with global_load_lds_dwordx4 (no staging registers, no ds_write, one
-//              barrier per level; rings one slot deeper so that the copy of the next plane can run under the whole
-//              compute phase). Needs 16-byte aligned rows: icells % (16/sizeof(TF)) == 0 and 16-byte aligned fields.
-// DMA = false: planes are staged through registers (prefetch, two barriers per level): any alignment.
-// PB = 16 : LDS-DMA in 16-byte pieces (rows 16-byte aligned); PB = 4: LDS-DMA in 4-byte pieces (global_load_lds_dword):
-//           any layout, four times the copy instructions; PB = 0: register-staged.
+#ifndef MHH_MARCH_UNROLL_F32
+#define MHH_MARCH_UNROLL_F32 0    // fp32: 1 = the rotated six-level groups of the fp64 form
+#endif
+// PB = 16 : LDS-DMA in 16-byte pieces (global_load_lds_dwordx4; rows and fields 16-byte aligned, no staging registers, no
+//           ds_write); PB = 4: in 4-byte pieces (global_load_lds_dword): any layout, four times the copy instructions.
 // ADV / DIF: which operator's terms are added -- both (the fused pass), or one of them: Advec::exec and Diff::exec as
 // separate calls then run the same kernel body (same bits, same order of accumulation as the fused pass in two steps).
 template<class TF, int NJ, bool HAS_S, int PB, bool ADV = true, bool DIF = true>
 __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : MHH_MARCH_OCC)) rhs25_march_kernel(const GridDev<TF> g, const MarchFields<TF> f, const MarchTiling mt)
 {
-    constexpr bool DMA = (PB != 0);
+    static_assert(PB == 16 || PB == 4, "piece size of the LDS-DMA copies");
     constexpr int VEC = 16 / (int)sizeof(TF);                       // elements per 16-byte DMA piece
     constexpr int AL = (PB == 16) ? VEC : 1;                        // granularity of tile widths / origins in elements
     constexpr int TI = ((70 + AL-1)/AL)*AL;                         // u,v,w,s tile: x from i0-3
@@ -105,14 +128,12 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
     constexpr int TE = ((64 + EX + 1 + AL-1)/AL)*AL;
     constexpr int TJ = NJ + 6, TJE = NJ + 2, NT = 64*NJ;
     constexpr int NTILE = TI*TJ, NETILE = TE*TJE;
-    constexpr int RU = DMA ? 3 : 2, RW = DMA ? 3 : 2, RE = DMA ? 4 : 3, RS = DMA ? 2 : 1;
-    // LDS rings: only the planes a level reads with horizontal offsets are kept -- u, v: k-1 and k (their k+1 values
-    // are needed at the thread's own column only: register window); w: k and k+1; evisc: k-1..k+1; scalar: k.
-    __shared__ __attribute__((aligned(16))) TF U[RU][NTILE];
-    __shared__ __attribute__((aligned(16))) TF V[RU][NTILE];
-    __shared__ __attribute__((aligned(16))) TF W[RW][NTILE];
-    __shared__ __attribute__((aligned(16))) TF S[HAS_S ? RS : 1][HAS_S ? NTILE : VEC];
-    __shared__ __attribute__((aligned(16))) TF E[DIF ? RE : 1][DIF ? NETILE : VEC];
+    // LDS rings, one slot deeper than what a level reads so that the copy of the next plane runs under the whole compute
+    // phase: u, v, s: level k; w: k and k+1; evisc: k-1..k+1. One array, so that every plane is a compile-time offset from
+    // one base (ds_read immediates; the LDS-DMA destination is base + constant).
+    constexpr int RU = 2, RW = 3, RE = DIF ? 4 : 0, RS = HAS_S ? 2 : 0;
+    constexpr int OU = 0, OV = OU + RU*NTILE, OW = OV + RU*NTILE, OS = OW + RW*NTILE, OE = OS + RS*NTILE, LTOT = OE + RE*NETILE;
+    __shared__ __attribute__((aligned(16))) TF L[LTOT];
 
     int bx, by, kcn;
     if (!decode_march(mt, blockIdx.x, bx, by, kcn)) return;        // whole block leaves together: no barrier hazard
@@ -126,220 +147,214 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
     const int ci = (i < g.iend) ? i : g.iend-1, cj = (j < mt.jlim) ? j : mt.jlim-1;   // clamped column for the window loads
     const int col = ci + cj*jj;
     const int ij = col;
-    // tendencies are touched once per kernel: their loads and stores carry the non-temporal hint, so that they stream past L2
-    // instead of evicting the field planes that neighbouring tiles re-read (512^3: HBM fetch 15.4 -> 14.1 GB per launch, same
-    // time; -DMHH_MARCH_NO_NT for A/B runs)
-#ifndef MHH_MARCH_NO_NT
-    auto tld = [](const TF* q) -> TF { return stream_load(q); };
-    auto tst = [](TF* q, TF v) { stream_store(q, v); };
-#else
-    auto tld = [](const TF* q) -> TF { return *q; };
-    auto tst = [](TF* q, TF v) { *q = v; };
-#endif
     const int l = (ty+3)*TI + (tx+3), le = (ty+1)*TE + (tx+EX);
-    auto slot = [](int p, int r) { return (p + 12) % r; };            // 12 is a multiple of every ring depth
+
+    // interior level of an updating iteration: faces k and k+1 of the centred fields and the w "faces" k-1, k all 6th order
+    int kf0 = (kb > g.kstart+3) ? kb : g.kstart+3;                 // first interior level of the chunk
+    int kf1 = (ke < g.kend-3) ? ke : g.kend-3;                     // one past its last
+#ifdef MHH_MARCH_NO_FAST    // A/B builds only
+    kf0 = kf1 = ke;
+#endif
+    if (kf1 < kf0) kf1 = kf0;
+    if (kf0 > ke) kf0 = kf1 = ke;
+    // ring slot of plane p: counted from the first level of the rotated groups, so that inside a group of six the slots of
+    // the 2- and 3-deep rings are compile-time constants (12 is a multiple of every ring depth; planes from kb-2 on are
+    // copied: p - kg0 >= -5)
+    const int kg0 = (kf0 - kb <= 3) ? kf0 : kb;
+    auto slot = [&](int p, int r) { return (p - kg0 + 12) % r; };
+
+    // ---- wave-uniform values of the interior loop, each pinned in scalar registers of its own. Without this the compiler
+    // keeps the kernel-argument structs as the 16-dword tuples its merged s_loads produced, spills them whole and restores
+    // all sixteen dwords (v_readlane: a VECTOR instruction each) to use one pointer -- ~190 of them per level. ------------
+    const size_t kk8 = sgpr((size_t)kk * sizeof(TF));              // bytes per plane
+    auto adv = [&](const TF* q, int n) -> const TF* { return reinterpret_cast<const TF*>(reinterpret_cast<const char*>(q) + n*kk8); };
+    const TF dxih = sgpr(f.dxih), dyih = sgpr(f.dyih), dxi = sgpr(f.dxi), dyi = sgpr(f.dyi);
+    const TF dxd = sgpr(f.dxd), dyd = sgpr(f.dyd), dxd2 = sgpr(f.dxd2), dyd2 = sgpr(f.dyd2);
+    const TF dxidxi = sgpr(f.dxidxi), dyidyi = sgpr(f.dyidyi);
+    const TF visc = sgpr(f.visc), svisc = sgpr(f.svisc), tPr2 = sgpr(f.tPr2), rtPr2 = sgpr(f.rtPr2);
+    const TF* __restrict__ tdzi = sgpr(g.dzi); const TF* __restrict__ tdzhi = sgpr(g.dzhi);
+    auto div_tpr = [&](TF x) -> TF { return div_known(x, tPr2, rtPr2); };     // 0.5*x / tPr
 
     // ---- tile movers. A tile is walked in pieces of PW 32-bit words: e = tid + n*NT; piece -> (row, first word) --------
     constexpr int EW = (int)sizeof(TF) / 4;                           // words per element
-    constexpr int PW = DMA ? PB/4 : EW;                               // words per piece (staged: one element)
+    constexpr int PW = PB/4;                                          // words per piece
     constexpr int PPR = TI*EW / PW, PPRE = TE*EW / PW;                // pieces per tile row
     constexpr int NP = PPR*TJ, NPE = PPRE*TJE;
     constexpr int NLD = (NP + NT - 1) / NT, NLDE = (NPE + NT - 1) / NT;
-    int off[NLD], offe[NLDE];                                         // word offsets from the start of a plane
-    bool okt[NLD], oke[NLDE];
+    // Every lane's piece lies inside the array: tiles that stick out over the east / north edge of the array (ragged grids)
+    // copy the array's last pieces / rows instead -- those LDS cells are read by inactive threads only -- so no lane mask is
+    // needed but for the one wave per sweep that straddles the end of the tile.
+    unsigned off[NLD], offe[NLDE > 0 ? NLDE : 1];                     // byte offsets from the start of a plane
 #pragma unroll
     for (int n=0; n<NLD; ++n)
     {
-        const int e = tid + n*NT;
+        const int e = (tid + n*NT < NP) ? tid + n*NT : NP-1;
         const int tj = e / PPR, tw = (e - tj*PPR)*PW;
-        const int gw = (i0 - 3)*EW + tw, gj = j0 - 3 + tj;
-        okt[n] = (e < NP) && (gw + PW <= g.icells*EW) && (gj < g.jcells);
-        off[n] = okt[n] ? gw + gj*jj*EW : 0;
+        int gw = (i0 - 3)*EW + tw, gj = j0 - 3 + tj;
+        if (gw + PW > g.icells*EW) gw = g.icells*EW - PW;
+        if (gj >= g.jcells) gj = g.jcells - 1;
+        off[n] = (unsigned)(gw + gj*jj*EW) * 4u;
     }
 #pragma unroll
     for (int n=0; n<NLDE; ++n)
     {
-        const int e = tid + n*NT;
+        const int e = (tid + n*NT < NPE) ? tid + n*NT : NPE-1;
         const int tj = e / PPRE, tw = (e - tj*PPRE)*PW;
-        const int gw = (i0 - EX)*EW + tw, gj = j0 - 1 + tj;
-        oke[n] = (e < NPE) && (gw + PW <= g.icells*EW) && (gj < g.jcells);
-        offe[n] = oke[n] ? gw + gj*jj*EW : 0;
+        int gw = (i0 - EX)*EW + tw, gj = j0 - 1 + tj;
+        if (gw + PW > g.icells*EW) gw = g.icells*EW - PW;
+        if (gj >= g.jcells) gj = g.jcells - 1;
+        offe[n] = (unsigned)(gw + gj*jj*EW) * 4u;
     }
-    // register-staged movers
-    auto ld_tile = [&](const TF* __restrict__ fld, int kp, TF (&r)[NLD])
-    {
-        const bool kok = (kp >= 0) && (kp < g.kcells);
-        const TF* __restrict__ pl = fld + (kok ? (size_t)kp*kk : 0);
-#pragma unroll
-        for (int n=0; n<NLD; ++n) r[n] = (kok && okt[n]) ? pl[off[n]/EW] : TF(0);
-    };
-    auto st_tile = [&](TF* __restrict__ lds, const TF (&r)[NLD])
-    {
-#pragma unroll
-        for (int n=0; n<NLD; ++n) { const int e = tid + n*NT; if (n+1 < NLD || e < NP) lds[e] = r[n]; }
-    };
-    auto ld_etile = [&](int kp, TF (&r)[NLDE])
-    {
-        const bool kok = (kp >= 0) && (kp < g.kcells);
-        const TF* __restrict__ pl = f.ev + (kok ? (size_t)kp*kk : 0);
-#pragma unroll
-        for (int n=0; n<NLDE; ++n) r[n] = (kok && oke[n]) ? pl[offe[n]/EW] : TF(0);
-    };
-    auto st_etile = [&](TF* __restrict__ lds, const TF (&r)[NLDE])
-    {
-#pragma unroll
-        for (int n=0; n<NLDE; ++n) { const int e = tid + n*NT; if (n+1 < NLDE || e < NPE) lds[e] = r[n]; }
-    };
-    // LDS-DMA movers: PB bytes per lane straight into the ring slot; lanes outside the tile / the array sit out
+    // LDS-DMA movers: PB bytes per lane straight into the ring slot
     const int wave_e0 = tid & ~63;                                    // first piece index of this wave within a sweep
     // SV: the copy as scalar base + per-lane byte offset + scalar LDS address (gfx950_prims.h): no vector ALU per piece
 #ifdef MHH_DMA_NO_SV
     constexpr bool SV = false;
 #else
-    constexpr bool SV = DMA && (MHH_RAW_DMA != 0);
+    constexpr bool SV = (MHH_RAW_DMA != 0);
 #endif
-    const unsigned wave_lds = uniform_u32((unsigned)(wave_e0*PW*4));
-    auto dma_piece = [&](const TF* plane, int word_off, TF* lds, int n)
+    const unsigned lds_wave = sgpr(lds_address(L) + uniform_u32((unsigned)(wave_e0*PW*4)));   // this wave's lane-0 byte address in L
+    // lo = element offset of the destination tile in L
+    auto dma_piece = [&](const TF* plane, unsigned byte_off, int lo, int n)
     {
-        if constexpr (SV) lds_dma_sv<PB>(plane, (unsigned)word_off*4u, lds_address(lds) + (wave_lds + (unsigned)(n*NT*PW*4)));
+        if constexpr (SV) lds_dma_sv2<PB>(plane, byte_off, lds_wave, (unsigned)(lo*(int)sizeof(TF) + n*NT*PW*4));
         else
         {
-            const uint32_t* src = reinterpret_cast<const uint32_t*>(plane) + word_off;
-            uint32_t* dst = reinterpret_cast<uint32_t*>(lds) + (size_t)(wave_e0 + n*NT)*PW;
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(plane) + byte_off/4u;
+            uint32_t* dst = reinterpret_cast<uint32_t*>(L + lo) + (size_t)(wave_e0 + n*NT)*PW;
             if constexpr (PB == 16) lds_dma16<(sizeof(TF) == 8)>(src, dst); else lds_dma4<(sizeof(TF) == 8)>(src, dst);
         }
     };
-    auto dma_tile = [&](const TF* __restrict__ fld, int kp, TF* __restrict__ lds)
+    // pl = the plane to copy (a wave-uniform pointer inside the array)
+    auto dma_tile = [&](const TF* __restrict__ pl, int lo)
     {
-        if (kp < 0 || kp >= g.kcells) return;                         // wave-uniform
-        const TF* __restrict__ pl = fld + (size_t)kp*kk;
 #pragma unroll
         for (int n=0; n<NLD; ++n)
-            if (okt[n]) dma_piece(pl, off[n], lds, n);
+            if ((n+1)*NT <= NP || tid + n*NT < NP) dma_piece(pl, off[n], lo, n);
     };
-    auto dma_etile = [&](int kp, TF* __restrict__ lds)
+    auto dma_etile = [&](const TF* __restrict__ pl, int lo)
     {
-        if (kp < 0 || kp >= g.kcells) return;
-        const TF* __restrict__ pl = f.ev + (size_t)kp*kk;
 #pragma unroll
         for (int n=0; n<NLDE; ++n)
-            if (oke[n]) dma_piece(pl, offe[n], lds, n);
+            if ((n+1)*NT <= NPE || tid + n*NT < NPE) dma_piece(pl, offe[n], lo, n);
     };
-    auto colval = [&](const TF* __restrict__ fld, int kp) -> TF
+    const int kmaxp = g.kcells - 1;                                   // planes are clamped into [0, kcells-1]: values read from a
+    auto plane = [&](const TF* __restrict__ fld, int kp) -> const TF*   // clamped plane are never used by an updated level
     {
-        return (kp >= 0 && kp < g.kcells) ? fld[col + kp*kk] : TF(0);
+        const int kq = kp < 0 ? 0 : (kp > kmaxp ? kmaxp : kp);
+        return fld + (size_t)kq*kk;
     };
+    // column values and tendencies go through scalar base + 32-bit lane byte offset (gload / gstore, gfx950_prims.h).
+    // Tendencies are touched once per kernel: their loads and stores carry the non-temporal hint, so that they stream past L2
+    // instead of evicting the field planes that neighbouring tiles re-read (512^3: HBM fetch 15.4 -> 14.1 GB per launch, same
+    // time; -DMHH_MARCH_NO_NT for A/B runs)
+#ifndef MHH_MARCH_NO_NT
+    auto tld = [](const TF* base, unsigned bo) -> TF { return gload_stream(base, bo); };
+    auto tst = [](TF* base, unsigned bo, TF v) { gstore_stream(base, bo, v); };
+#else
+    auto tld = [](const TF* base, unsigned bo) -> TF { return gload(base, bo); };
+    auto tst = [](TF* base, unsigned bo, TF v) { gstore(base, bo, v); };
+#endif
+    unsigned bo0 = (unsigned)col * (unsigned)sizeof(TF);              // this column in a plane, one / two / three planes up
+    unsigned bo1 = (unsigned)(col + kk) * (unsigned)sizeof(TF), bo2 = (unsigned)(col + 2*kk) * (unsigned)sizeof(TF);
+    unsigned bo3 = (unsigned)(col + 3*kk) * (unsigned)sizeof(TF);
 
-    // ---- prologue: the planes level ks reads, scalar plane ks, windows centred on ks ------------------------------
+    // ---- prologue: the planes level ks reads, windows centred on ks ----------------------------------------------------
     const int ks = kb - 1;                 // warm-up level: only top-face quantities are formed there
-    if constexpr (DMA)
-    {
-        for (int p = ks-1; p <= ks+1; ++p)
-        {
-            if (p <= ks) { dma_tile(f.u, p, U[slot(p, RU)]); dma_tile(f.v, p, V[slot(p, RU)]); }
-            if (p >= ks) dma_tile(f.w, p, W[slot(p, RW)]);
-            if (DIF) dma_etile(p, E[slot(p, RE)]);
-        }
-        if (HAS_S) dma_tile(f.s, ks, S[slot(ks, RS)]);
-    }
-    else
-    {
-        TF r[NLD]; TF re[NLDE];
-        for (int p = ks-1; p <= ks+1; ++p)
-        {
-            if (p <= ks) { ld_tile(f.u, p, r); st_tile(U[slot(p, RU)], r); ld_tile(f.v, p, r); st_tile(V[slot(p, RU)], r); }
-            if (p >= ks) { ld_tile(f.w, p, r); st_tile(W[slot(p, RW)], r); }
-            if (DIF) { ld_etile(p, re);    st_etile(E[slot(p, RE)], re); }
-        }
-        if (HAS_S) { ld_tile(f.s, ks, r); st_tile(S[0], r); }
-    }
-    TF uw[7], vw[7], ww[7], sw[7];
+    dma_tile(plane(f.u, ks), OU + slot(ks, RU)*NTILE); dma_tile(plane(f.v, ks), OV + slot(ks, RU)*NTILE);
+    dma_tile(plane(f.w, ks), OW + slot(ks, RW)*NTILE); dma_tile(plane(f.w, ks+1), OW + slot(ks+1, RW)*NTILE);
+    if constexpr (DIF) for (int p = ks-1; p <= ks+1; ++p) dma_etile(plane(f.ev, p), OE + slot(p, RE)*NETILE);
+    if constexpr (HAS_S) dma_tile(plane(f.s, ks), OS + slot(ks, RS)*NTILE);
+    TF uw[6], vw[6], ww[6], sw[6];         // levels ks-2 .. ks+3
 #pragma unroll
-    for (int n=0; n<7; ++n)
+    for (int n=0; n<6; ++n)
     {
-        uw[n] = colval(f.u, ks-3+n); vw[n] = colval(f.v, ks-3+n); ww[n] = colval(f.w, ks-3+n);
-        sw[n] = HAS_S ? colval(f.s, ks-3+n) : TF(0);
+        uw[n] = plane(f.u, ks-2+n)[col]; vw[n] = plane(f.v, ks-2+n)[col]; ww[n] = plane(f.w, ks-2+n)[col];
+        sw[n] = HAS_S ? plane(f.s, ks-2+n)[col] : TF(0);
     }
-    if constexpr (DMA) wait_vmem();
+    // running plane pointers (wave-uniform): at level k, pu / pv / ps point at plane k+1, pw / pe at plane k+2 (the planes
+    // to copy; the window values of level k+4 are three / two planes further up), the tendencies' at plane k
+    const TF* pu = sgpr(f.u + (size_t)(ks+1)*kk); const TF* pv = sgpr(f.v + (size_t)(ks+1)*kk); const TF* pw = sgpr(f.w + (size_t)(ks+2)*kk);
+    const TF* ps = HAS_S ? sgpr(f.s + (size_t)(ks+1)*kk) : nullptr; const TF* pe = DIF ? sgpr(f.ev + (size_t)(ks+2)*kk) : nullptr;
+    TF* put = sgpr(f.ut + (long long)ks*kk); TF* pvt = sgpr(f.vt + (long long)ks*kk); TF* pwt = sgpr(f.wt + (long long)ks*kk);
+    TF* pst = HAS_S ? sgpr(f.st + (long long)ks*kk) : nullptr;
+    wait_vmem();
     __syncthreads();
 
-    // carried bottom-face products: advective centred (T) and upwind (G) parts, diffusive flux (D)
+    // carried bottom-face products: advective centred (T) and upwind (G) parts, diffusive flux (D); the advective ones of
+    // u, v, w hold TWICE the reference's face product (the advecting velocity enters as the sum of the two values it averages)
     TF cTu = 0, cGu = 0, cDu = 0, cTv = 0, cGv = 0, cDv = 0, cTw = 0, cGw = 0, cDw = 0, cTs = 0, cGs = 0, cDs = 0;
+    TF u1m = 0, vNm = 0;                   // u(i+1), v(j+1) of the level below (the w equation's faces)
 
     // Latency of the tendency read-modify-writes (fp64 form; the fp32 form has no registers to spare at four waves per SIMD):
     //  * TPREF: the tendencies of the NEXT level are loaded a whole level ahead of their use, like the LDS-DMA planes;
     //  * DSTORE: the last tendency finished in a level (the scalar's) is stored at the top of the next level, so that the
     //    s_waitcnt vmcnt(0) in front of the barrier -- which on gfx9 also waits for stores -- does not find it just issued.
-    //    (1: all four deferred -- spills; 2: w and scalar; 3: scalar only.)
-    // 512^3: 6.05 -> 5.75 (TPREF) -> 5.67 ms (DSTORE 3), 225 -> 245 VGPRs, still two waves per SIMD and no scratch.
 #ifndef MHH_MARCH_TPREF
 #define MHH_MARCH_TPREF 1
 #endif
 #ifndef MHH_MARCH_DSTORE
-#define MHH_MARCH_DSTORE 3
+#define MHH_MARCH_DSTORE 1
 #endif
     constexpr bool TPREF = (sizeof(TF) == 8) && (MHH_MARCH_TPREF != 0);
-    constexpr int DSTORE = (sizeof(TF) == 8) ? MHH_MARCH_DSTORE : 0;       // 0: every store where its value is finished
-    TF dsu = 0, dsv = 0, dsw = 0, dss = 0; int dsk = -1; bool dsw_on = false;
+    constexpr bool DSTORE = (sizeof(TF) == 8) && HAS_S && (MHH_MARCH_DSTORE != 0);
+    TF dss = 0; bool dsp = false;          // deferred scalar tendency of the level below
     TF tpu = 0, tpv = 0, tpw = 0, tps = 0;
-    const TF dxi = g.dxi_t, dyi = g.dyi_t;          // advection spelling TF(1.)/dx
-    const TF dxd = g.dxi_d, dyd = g.dyi_d;          // diffusion spelling TF(1./dx)
-    const TF visc = f.visc;
 
-#ifdef MHH_MARCH_STAMPS
-    unsigned long long stamp_acc[8] = {0,0,0,0,0,0,0,0}; unsigned long long stamp_t = clock64();
-#endif
     // One level. FAST = an interior level of an updating iteration: every vertical face is 6th/5th order, no wall or
     // surface-flux branch applies -- the face orders and the wall predicates become constants and their dispatch
     // (a third of the loop's scalar / control instructions) disappears. Same arithmetic either way.
     // RHO1 = rhoref and rhorefh are exactly 1 on every level this block touches (Boussinesq base state): 1*x and x/1 are x,
     // bit for bit, so the density factors and divisions drop out of the instantiation instead of being tested per use.
-    auto level = [&](const int k, auto fast_tag, auto rho1_tag)
+    // ROT = rotation of the register windows (0..5), or -1: rotation 0 and a physical shift at the end of the level.
+    auto level = [&](const int k, auto fast_tag, auto rho1_tag, auto rot_tag) __attribute__((always_inline))
     {
         constexpr bool FAST = decltype(fast_tag)::value, RHO1 = decltype(rho1_tag)::value;
+        constexpr int ROT = decltype(rot_tag)::value, RR = (ROT < 0) ? 0 : ROT;
         auto R = [](TF r, TF x) { return RHO1 ? x : r*x; };
-        STAMP(0);
-        // ---- start moving the next level's planes: k+1 of u, v, s; k+2 of w, evisc; window value k+4 ---------------
-        TF pu[NLD], pv[NLD], pw[NLD], ps[NLD], pe[NLDE];        // staging registers (unused, and removed, in the DMA variant)
+        // ring slot of plane k+d: inside a rotated group k - kg0 = ROT (mod 6), a constant for the rings whose depth divides 6
+        auto sl = [&](int d, int r) { return (ROT >= 0 && 6 % r == 0) ? (ROT + d + 12) % r : slot(k + d, r); };
+        // the lane offsets of the column accesses, re-defined (by nothing) in every level: as loop invariants their zero
+        // extension to 64 bits is hoisted, and the accesses then take 64-bit vector addresses (v_lshl_add_u64 each, two
+        // registers per offset) instead of the scalar-base + 32-bit-offset form
+        keep_vgpr(bo0); keep_vgpr(bo1); keep_vgpr(bo2); keep_vgpr(bo3);
+        // ---- start moving the next level's planes: k+1 of u, v, s; k+2 of w, evisc; window value k+4 -------------------
         const bool more = (k + 1 < ke);
         if (more)
         {
-            if constexpr (DMA)
-            {
-                dma_tile(f.u, k+1, U[slot(k+1, RU)]); dma_tile(f.v, k+1, V[slot(k+1, RU)]); dma_tile(f.w, k+2, W[slot(k+2, RW)]);
-                if (DIF) dma_etile(k+2, E[slot(k+2, RE)]);
-                if (HAS_S) dma_tile(f.s, k+1, S[slot(k+1, RS)]);
-            }
-            else
-            {
-                ld_tile(f.u, k+1, pu); ld_tile(f.v, k+1, pv); ld_tile(f.w, k+2, pw); if (DIF) ld_etile(k+2, pe);
-                if (HAS_S) ld_tile(f.s, k+1, ps);
-            }
+            // more: k+2 <= ke <= kend lies inside the array
+            dma_tile(pu, OU + sl(1, RU)*NTILE); dma_tile(pv, OV + sl(1, RU)*NTILE); dma_tile(pw, OW + sl(2, RW)*NTILE);
+            if constexpr (DIF) dma_etile(pe, OE + sl(2, RE)*NETILE);
+            if constexpr (HAS_S) dma_tile(ps, OS + sl(1, RS)*NTILE);
         }
-        const TF nu = more ? colval(f.u, k+4) : TF(0), nv = more ? colval(f.v, k+4) : TF(0), nw = more ? colval(f.w, k+4) : TF(0);
-        const TF ns = (more && HAS_S) ? colval(f.s, k+4) : TF(0);
-        if (DSTORE && dsk >= 0 && active)
-        {
-            const int cd = col + dsk*kk;
-            if (DSTORE == 1) { tst(f.ut + cd, dsu); tst(f.vt + cd, dsv); }
-            if (DSTORE <= 2 && dsw_on) tst(f.wt + cd, dsw);
-            if (HAS_S) tst(f.st + cd, dss);
-        }
-        dsk = -1;
+        // window values of level k+4, read unconditionally (no select, no copy): past the top of the array the plane pointer
+        // steps back onto the last plane -- such values only enter faces above the top wall, which are never formed
+        const int over = (k + 4 > kmaxp) ? kmaxp - (k + 4) : 0;    // <= 0
+        const TF nu = gload(adv(pu, over), bo3), nv = gload(adv(pv, over), bo3), nw = gload(adv(pw, over), bo2);
+        const TF ns = HAS_S ? gload(adv(ps, over), bo3) : TF(0);
+        if (DSTORE && dsp && active) tst(const_cast<TF*>(adv(pst, -1)), bo0, dss);   // the scalar tendency of level k-1
+        dsp = false;
         const TF tcu = tpu, tcv = tpv, tcw = tpw, tcs = tps;      // this level's tendencies (loaded during the previous level)
-        if (TPREF && more && active) {     // the warm-up level ks = kb-1 fetches those of kb
-            const int cn = col + (k+1)*kk; tpu = tld(f.ut + cn); tpv = tld(f.vt + cn); tpw = tld(f.wt + cn); if (HAS_S) tps = tld(f.st + cn); }
+        if constexpr (TPREF) {             // the warm-up level ks = kb-1 fetches those of kb. Unconditional: inactive lanes sit on
+            // a clamped (valid) column and plane k+1 <= kend exists, so no lane mask, no select, no register copy
+            tpu = tld(put, bo1); tpv = tld(pvt, bo1); tpw = tld(pwt, bo1); if constexpr (HAS_S) tps = tld(pst, bo1); }
 
-        const TF* __restrict__ uk = U[slot(k, RU)] + l;  const TF* __restrict__ ukm = U[slot(k-1, RU)] + l;
-        const TF* __restrict__ vk = V[slot(k, RU)] + l;  const TF* __restrict__ vkm = V[slot(k-1, RU)] + l;
-        const TF* __restrict__ wk = W[slot(k, RW)] + l;  const TF* __restrict__ wkp = W[slot(k+1, RW)] + l;
-        const TF* __restrict__ sk = S[HAS_S ? slot(k, RS) : 0] + (HAS_S ? l : 0);
-        const TF* __restrict__ ek = E[DIF ? slot(k, RE) : 0] + (DIF ? le : 0); const TF* __restrict__ ekm = E[DIF ? slot(k-1, RE) : 0] + (DIF ? le : 0);
-        const TF* __restrict__ ekp = E[DIF ? slot(k+1, RE) : 0] + (DIF ? le : 0);
-        // per-level coefficients (wave-uniform)
+        const TF* __restrict__ uk = L + OU + sl(0, RU)*NTILE + l;
+        const TF* __restrict__ vk = L + OV + sl(0, RU)*NTILE + l;
+        const TF* __restrict__ wk = L + OW + sl(0, RW)*NTILE + l;  const TF* __restrict__ wkp = L + OW + sl(1, RW)*NTILE + l;
+        const TF* __restrict__ sk = L + (HAS_S ? OS + sl(0, RS ? RS : 1)*NTILE + l : 0);
+        const TF* __restrict__ ek = L + (DIF ? OE + sl(0, RE ? RE : 1)*NETILE + le : 0);
+        const TF* __restrict__ ekm = L + (DIF ? OE + sl(-1, RE ? RE : 1)*NETILE + le : 0);
+        const TF* __restrict__ ekp = L + (DIF ? OE + sl(1, RE ? RE : 1)*NETILE + le : 0);
+        // the own column at k-1, k, k+1: from the register windows
+        const TF u0m = wv<RR,1>(uw), u0 = wv<RR,2>(uw), u0p = wv<RR,3>(uw);
+        const TF v0m = wv<RR,1>(vw), v0 = wv<RR,2>(vw), v0p = wv<RR,3>(vw);
+        const TF w0 = wv<RR,2>(ww), w0p = wv<RR,3>(ww);
+        const TF s0m = wv<RR,1>(sw), s0 = wv<RR,2>(sw), s0p = wv<RR,3>(sw);
         // per-level coefficients: scalar loads (uniform_load), not vector loads whose wait would drain the copies in flight
         const TF rhkp = RHO1 ? TF(1) : uniform_load(f.rhorefh, k+1), rhk = RHO1 ? TF(1) : uniform_load(f.rhorefh, k), rk = RHO1 ? TF(1) : uniform_load(f.rhoref, k);
-        const TF dzi = uniform_load(g.dzi, k), dzhi = uniform_load(g.dzhi, k), dzhip = uniform_load(g.dzhi, k+1);
+        const TF dzi = uniform_load(tdzi, k), dzhi = uniform_load(tdzhi, k), dzhip = uniform_load(tdzhi, k+1);
+        const TF dzih = scale2<-1>(dzi), dzhih = scale2<-1>(dzhi), dzhi2 = scale2<1>(dzhi);
         const bool rk1 = RHO1 || (rk == TF(1.)), rhk1 = RHO1 || (rhk == TF(1.));
         const int otc = FAST ? 6 : order_face_c(k+1, g.kstart, g.kend);
         const int obc = FAST ? 6 : order_face_c(k, g.kstart, g.kend);
@@ -350,117 +365,110 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
         const bool fb = !FAST && f.sm && (k == g.kstart), ft = !FAST && f.sm && (k == g.kend-1);
         const bool need_dtop = FAST || (!(ft) && (k < g.kend-1 || !f.sm) && (k+1 <= g.kend));   // top diffusive flux of level k is used by k or k+1
 
-        STAMP(1);
+        const TF u_e = uk[1], v_n = vk[TI];                      // also next level's u1m, vNm
+
         // ---- top-face quantities of level k --------------------------------------------------------------------
         TF Tu = 0, Gu = 0, Tv = 0, Gv = 0, Tw = 0, Gw = 0, Ts = 0, Gs = 0;
         if (ADV && otc != 0)
         {
-            const TF wtu = i2(wkp[-1], wkp[0]);
-            const TF wtv = i2(wkp[-TI], wkp[0]);
-            Tu = R(rhkp, wtu) * win_cen(uw, otc);
-            Tv = R(rhkp, wtv) * win_cen(vw, otc);
-            if (otc >= 4) { Gu = R(rhkp, tabs(wtu)) * win_upw(uw, otc); Gv = R(rhkp, tabs(wtv)) * win_upw(vw, otc); }
+            const TF swu = wkp[-1] + w0p;                        // 2 x the advecting w at the u / v point
+            const TF swv = wkp[-TI] + w0p;
+            Tu = R(rhkp, swu) * win_cen<RR>(uw, otc);
+            Tv = R(rhkp, swv) * win_cen<RR>(vw, otc);
+            if (otc >= 4) { Gu = R(rhkp, tabs(swu)) * win_upw<RR>(uw, otc); Gv = R(rhkp, tabs(swv)) * win_upw<RR>(vw, otc); }
             if (HAS_S)
             {
-                Ts = R(rhkp, ww[4]) * win_cen(sw, otc);
-                if (otc >= 4) Gs = R(rhkp, tabs(ww[4])) * win_upw(sw, otc);
+                Ts = R(rhkp, w0p) * win_cen<RR>(sw, otc);
+                if (otc >= 4) Gs = R(rhkp, tabs(w0p)) * win_upw<RR>(sw, otc);
             }
         }
         if (ADV && wlev)
         {
-            const TF wtw = i2(ww[3], ww[4]);
-            Tw = R(rk, wtw) * win_cen(ww, otw);
-            if (otw >= 4) Gw = R(rk, tabs(wtw)) * win_upw(ww, otw);
+            const TF sww = w0 + w0p;
+            Tw = R(rk, sww) * win_cen<RR>(ww, otw);
+            if (otw >= 4) Gw = R(rk, tabs(sww)) * win_upw<RR>(ww, otw);
         }
         TF Du = 0, Dv = 0, Dw = 0, Ds = 0;
         if (DIF && need_dtop)
         {
             const TF etu = TF(0.25)*(ek[-1] + ek[0] + ekp[-1] + ekp[0]) + visc;
-            Du = R(rhkp, etu)*((uw[4]-uw[3])*dzhip + (wkp[0]-wkp[-1])*dxd);
+            Du = R(rhkp, etu)*((u0p-u0)*dzhip + (w0p-wkp[-1])*dxd);
             const TF etv = TF(0.25)*(ek[-TE] + ek[0] + ekp[-TE] + ekp[0]) + visc;
-            Dv = R(rhkp, etv)*((vw[4]-vw[3])*dzhip + (wkp[0]-wkp[-TI])*dyd);
+            Dv = R(rhkp, etv)*((v0p-v0)*dzhip + (w0p-wkp[-TI])*dyd);
             if (HAS_S)
             {
-                const TF ets = TF(0.5)*(ek[0]+ekp[0])/f.tPr + f.svisc;
-                Ds = R(rhkp, ets)*(sw[4]-sw[3])*dzhip;
+                const TF ets = div_tpr(ek[0]+ekp[0]) + svisc;
+                Ds = R(rhkp, ets)*(s0p-s0)*dzhip;
             }
         }
         if (DIF && wlev)
         {
             const TF etw = ek[0] + visc;
-            Dw = R(rk, etw)*(ww[4]-ww[3])*dzi;
+            Dw = R(rk, etw)*(w0p-w0)*dzi;
         }
 
-        STAMP(2);
         // ---- update the tendencies of level k ----------------------------------------------------------------
+        // (sched_fence between the field sections: the instruction scheduler otherwise hoists every LDS read of a level to
+        //  its top and the level needs more than the 256 registers of two waves per SIMD)
         if ((FAST || k >= kb) && active)
         {
-            const int c = col + k*kk;
+            sched_fence();
             {   // u
-                TF ue = 0, uwf = 0, vn = 0, vs = 0;
-                if constexpr (ADV) { ue = i2(uk[0], uk[1]); uwf = i2(uk[-1], uk[0]);
-                                     vn = i2(vk[TI-1], vk[TI]); vs = i2(vk[-1], vk[0]); }
-                TF t = TPREF ? tcu : tld(f.ut + c);
+                TF t = TPREF ? tcu : tld(put, bo0);
                 if constexpr (ADV)
                 {
-                    t += advec25_hor(uk, 0, TI, ue, uwf, vn, vs, dxi, dyi);
-                    t += vert_combine(otc, obc, Tu, cTu, Gu, cGu, rk, rk1, dzi);
+                    t += advec25_hor_f0(uk, u0, TI, u0 + u_e, uk[-1] + u0, vk[TI-1] + v_n, vk[-1] + v0, dxih, dyih);
+                    t += vert_combine(otc, obc, Tu, cTu, Gu, cGu, rk, rk1, dzih);
                 }
                 if constexpr (DIF)
                 {
                     const TF ee = ek[0] + visc, ew = ek[-1] + visc;
                     const TF en = TF(0.25)*(ek[-1   ] + ek[0  ] + ek[-1+TE] + ek[TE]) + visc;
                     const TF es = TF(0.25)*(ek[-1-TE] + ek[-TE] + ek[-1   ] + ek[0 ]) + visc;
-                    const TF hor = + ( ee*(uk[1]-uk[0])*dxd - ew*(uk[0]-uk[-1])*dxd ) * TF(2.)*dxd
-                                   + ( en*((uk[TI]-uk[0  ])*dyd + (vk[TI]-vk[TI-1])*dxd)
-                                     - es*((uk[0 ]-uk[-TI])*dyd + (vk[0 ]-vk[-1  ])*dxd) ) * dyd;
+                    const TF hor = + ( ee*(u_e-u0)*dxd - ew*(u0-uk[-1])*dxd ) * dxd2
+                                   + ( en*((uk[TI]-u0    )*dyd + (v_n-vk[TI-1])*dxd)
+                                     - es*((u0    -uk[-TI])*dyd + (v0 -vk[-1  ])*dxd) ) * dyd;
                     TF ver;
                     if (fb)      ver = div_rho( Du + rhk * f.ufb[ij], rk, rk1 ) * dzi;
                     else if (ft) ver = div_rho( - rhkp * f.uft[ij] - cDu, rk, rk1 ) * dzi;
                     else         ver = div_rho( Du - cDu, rk, rk1 ) * dzi;
                     t += hor + ver;
                 }
-                dsk = k;
-                if (DSTORE == 1) dsu = t; else tst(f.ut + c, t);
+                tst(put, bo0, t);
             }
+            sched_fence();
             {   // v
-                TF ue = 0, uwf = 0, vn = 0, vs = 0;
-                if constexpr (ADV) { ue = i2(uk[1-TI], uk[1]); uwf = i2(uk[-TI], uk[0]);
-                                     vn = i2(vk[0], vk[TI]); vs = i2(vk[-TI], vk[0]); }
-                TF t = TPREF ? tcv : tld(f.vt + c);
+                TF t = TPREF ? tcv : tld(pvt, bo0);
                 if constexpr (ADV)
                 {
-                    t += advec25_hor(vk, 0, TI, ue, uwf, vn, vs, dxi, dyi);
-                    t += vert_combine(otc, obc, Tv, cTv, Gv, cGv, rk, rk1, dzi);
+                    t += advec25_hor_f0(vk, v0, TI, uk[1-TI] + u_e, uk[-TI] + u0, v0 + v_n, vk[-TI] + v0, dxih, dyih);
+                    t += vert_combine(otc, obc, Tv, cTv, Gv, cGv, rk, rk1, dzih);
                 }
                 if constexpr (DIF)
                 {
                     const TF ee = TF(0.25)*(ek[-TE  ] + ek[0 ] + ek[1-TE] + ek[1]) + visc;
                     const TF ew = TF(0.25)*(ek[-1-TE] + ek[-1] + ek[-TE ] + ek[0]) + visc;
                     const TF en = ek[0] + visc, es = ek[-TE] + visc;
-                    const TF hor = + ( ee*((vk[1]-vk[0 ])*dxd + (uk[1]-uk[1-TI])*dyd)
-                                     - ew*((vk[0]-vk[-1])*dxd + (uk[0]-uk[-TI ])*dyd) ) * dxd
-                                   + ( en*(vk[TI]-vk[0])*dyd - es*(vk[0]-vk[-TI])*dyd ) * TF(2.)*dyd;
+                    const TF hor = + ( ee*((vk[1]-v0    )*dxd + (u_e-uk[1-TI])*dyd)
+                                     - ew*((v0   -vk[-1])*dxd + (u0 -uk[-TI ])*dyd) ) * dxd
+                                   + ( en*(v_n-v0)*dyd - es*(v0-vk[-TI])*dyd ) * dyd2;
                     TF ver;
                     if (fb)      ver = div_rho( Dv + rhk * f.vfb[ij], rk, rk1 ) * dzi;
                     else if (ft) ver = div_rho( - rhkp * f.vft[ij] - cDv, rk, rk1 ) * dzi;
                     else         ver = div_rho( Dv - cDv, rk, rk1 ) * dzi;
                     t += hor + ver;
                 }
-                if (DSTORE == 1) dsv = t; else tst(f.vt + c, t);
+                tst(pvt, bo0, t);
             }
-            dsw_on = (FAST || k > g.kstart);
+            sched_fence();
             if (FAST || k > g.kstart)
             {   // w
-                TF ue = 0, uwf = 0, vn = 0, vs = 0;
-                if constexpr (ADV) { ue = i2(ukm[1], uk[1]); uwf = i2(ukm[0], uk[0]);
-                                     vn = i2(vkm[TI], vk[TI]); vs = i2(vkm[0], vk[0]); }
-                TF t = TPREF ? tcw : tld(f.wt + c);
-                if (HAS_S && f.threfh) { const TF th_k = uniform_load(f.threfh, k); t += f.grav/th_k * (i2(sw[2], sw[3]) - th_k); }   // src/thermo_dry.cxx:165-178
+                TF t = TPREF ? tcw : tld(pwt, bo0);
+                if (HAS_S && f.threfh) { const TF th_k = uniform_load(f.threfh, k); t += f.grav/th_k * (i2(s0m, s0) - th_k); }   // src/thermo_dry.cxx:165-178
                 if constexpr (ADV)
                 {
-                    t += advec25_hor(wk, 0, TI, ue, uwf, vn, vs, dxi, dyi);
-                    t += vert_combine(otw, obw, Tw, cTw, Gw, cGw, rhk, rhk1, dzhi);
+                    t += advec25_hor_f0(wk, w0, TI, u1m + u_e, u0m + u0, vNm + v_n, v0m + v0, dxih, dyih);
+                    t += vert_combine(otw, obw, Tw, cTw, Gw, cGw, rhk, rhk1, dzhih);
                 }
                 if constexpr (DIF)
                 {
@@ -468,103 +476,99 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
                     const TF ew = TF(0.25)*(ekm[-1 ] + ek[-1 ] + ekm[0 ] + ek[0 ]) + visc;
                     const TF en = TF(0.25)*(ekm[0  ] + ek[0  ] + ekm[TE] + ek[TE]) + visc;
                     const TF es = TF(0.25)*(ekm[-TE] + ek[-TE] + ekm[0 ] + ek[0 ]) + visc;
-                    t += + ( ee*((wk[1 ]-wk[0  ])*dxd + (uk[1 ]-ukm[1 ])*dzhi)
-                           - ew*((wk[0 ]-wk[-1 ])*dxd + (uk[0 ]-ukm[0 ])*dzhi) ) * dxd
-                         + ( en*((wk[TI]-wk[0  ])*dyd + (vk[TI]-vkm[TI])*dzhi)
-                           - es*((wk[0 ]-wk[-TI])*dyd + (vk[0 ]-vkm[0 ])*dzhi) ) * dyd
-                         + div_rho( Dw - cDw, rhk, rhk1 ) * TF(2.)*dzhi;
+                    t += + ( ee*((wk[1 ]-w0     )*dxd + (u_e-u1m)*dzhi)
+                           - ew*((w0    -wk[-1 ])*dxd + (u0 -u0m)*dzhi) ) * dxd
+                         + ( en*((wk[TI]-w0     )*dyd + (v_n-vNm)*dzhi)
+                           - es*((w0    -wk[-TI])*dyd + (v0 -v0m)*dzhi) ) * dyd
+                         + div_rho( Dw - cDw, rhk, rhk1 ) * dzhi2;
                 }
-                if (DSTORE == 1 || DSTORE == 2) dsw = t; else tst(f.wt + c, t);
+                tst(pwt, bo0, t);
             }
-            if (HAS_S)
+            sched_fence();
+            if constexpr (HAS_S)
             {   // scalar
-                TF t = TPREF ? tcs : tld(f.st + c);
+                TF t = TPREF ? tcs : tld(pst, bo0);
                 if constexpr (ADV)
                 {
-                    t += advec25_hor(sk, 0, TI, uk[1], uk[0], vk[TI], vk[0], dxi, dyi);
+                    t += advec25_hor_f0(sk, s0, TI, u_e, u0, v_n, v0, dxi, dyi);
                     t += vert_combine(otc, obc, Ts, cTs, Gs, cGs, rk, rk1, dzi);
                 }
                 if constexpr (DIF)
                 {
-                    const TF ee = TF(0.5)*(ek[0  ]+ek[1 ])/f.tPr + f.svisc;
-                    const TF ew = TF(0.5)*(ek[-1 ]+ek[0 ])/f.tPr + f.svisc;
-                    const TF en = TF(0.5)*(ek[0  ]+ek[TE])/f.tPr + f.svisc;
-                    const TF es = TF(0.5)*(ek[-TE]+ek[0 ])/f.tPr + f.svisc;
-                    const TF hor = + ( ee*(sk[1 ]-sk[0]) - ew*(sk[0]-sk[-1 ]) ) * g.dxidxi_d
-                                   + ( en*(sk[TI]-sk[0]) - es*(sk[0]-sk[-TI]) ) * g.dyidyi_d;
+                    const TF e0 = ek[0];
+                    const TF ee = div_tpr(e0     +ek[1 ]) + svisc;
+                    const TF ew = div_tpr(ek[-1 ]+e0    ) + svisc;
+                    const TF en = div_tpr(e0     +ek[TE]) + svisc;
+                    const TF es = div_tpr(ek[-TE]+e0    ) + svisc;
+                    const TF hor = + ( ee*(sk[1 ]-s0) - ew*(s0-sk[-1 ]) ) * dxidxi
+                                   + ( en*(sk[TI]-s0) - es*(s0-sk[-TI]) ) * dyidyi;
                     TF ver;
                     if (fb)      ver = div_rho( Ds + rhk * f.sfb[ij], rk, rk1 ) * dzi;
                     else if (ft) ver = div_rho( -rhkp * f.sft[ij] - cDs, rk, rk1 ) * dzi;
                     else         ver = div_rho( Ds - cDs, rk, rk1 ) * dzi;
                     t += hor + ver;
                 }
-                if (DSTORE) dss = t; else tst(f.st + c, t);
+                if (DSTORE) { dss = t; dsp = true; } else tst(pst, bo0, t);
             }
         }
-        STAMP(3);
-        // ---- carry the top faces down, rotate the rings, shift the windows --------------------------------------------
+        // ---- carry the top faces down, rotate the windows, advance the plane pointers ------------------------------------
         cTu = Tu; cGu = Gu; cDu = Du; cTv = Tv; cGv = Gv; cDv = Dv; cTw = Tw; cGw = Gw; cDw = Dw; cTs = Ts; cGs = Gs; cDs = Ds;
-        if constexpr (DMA)
-        {
-            // unconditional (also after the chunk's last level, where nothing is in flight): every path back to the loop head
-            // then carries a vmcnt(0) the compiler can see, and it inserts no wait of its own in the next level
-            wait_vmem();                                           // this wave's copies have landed (and its stores have left)
-            STAMP(4);
-            __syncthreads();                                       // ... everyone's have, and everyone is done with the oldest planes
-            STAMP(6);
-        }
-        if (more)
-        {
-            if constexpr (!DMA)
-            {
-                __syncthreads();                                   // everyone is done reading the planes that are about to be replaced
-                STAMP(4);
-                st_tile(U[slot(k+1, RU)], pu); st_tile(V[slot(k+1, RU)], pv); st_tile(W[slot(k+2, RW)], pw); if (DIF) st_etile(E[slot(k+2, RE)], pe);
-                if (HAS_S) st_tile(S[0], ps);
-                STAMP(5);
-                __syncthreads();
-                STAMP(6);
-            }
-            shift(uw, nu); shift(vw, nv); shift(ww, nw); shift(sw, ns);
-        }
+        u1m = u_e; vNm = v_n;
+        pu = adv(pu, 1); pv = adv(pv, 1); pw = adv(pw, 1); if constexpr (HAS_S) ps = adv(ps, 1); if constexpr (DIF) pe = adv(pe, 1);
+        put = const_cast<TF*>(adv(put, 1)); pvt = const_cast<TF*>(adv(pvt, 1)); pwt = const_cast<TF*>(adv(pwt, 1));
+        if constexpr (HAS_S) pst = const_cast<TF*>(adv(pst, 1));
+        // unconditional (also after the chunk's last level, where nothing is in flight): every path back to the loop head
+        // then carries a vmcnt(0) the compiler can see, and it inserts no wait of its own in the next level
+        wait_vmem();                                           // this wave's copies have landed (and its stores have left)
+        __syncthreads();                                       // ... everyone's have, and everyone is done with the oldest planes
+        if constexpr (ROT < 0) { shift6(uw, nu); shift6(vw, nv); shift6(ww, nw); shift6(sw, ns); }
+        else { uw[RR] = nu; vw[RR] = nv; ww[RR] = nw; sw[RR] = ns; }     // the slot of level k-2 takes level k+4: rotation RR+1
     };
+    using std::true_type; using std::false_type;
+    using Shift = std::integral_constant<int, -1>;
     bool rho_one = true;                                           // wave-uniform: scalar loads of the chunk's base state
     for (int k = ks; k <= ke; ++k) rho_one = rho_one && (f.rhoref[k] == TF(1.)) && (f.rhorefh[k] == TF(1.));
 #ifdef MHH_MARCH_NO_RHO1   // A/B builds only
     rho_one = false;
 #endif
-    for (int k = ks; k < ke; ++k)
+    auto chunk = [&](auto rho1_tag, auto unroll_tag) __attribute__((always_inline))
     {
-        // interior level of an updating iteration: faces k and k+1 of the centred fields and the w "faces" k-1, k all 6th order
-#ifdef MHH_MARCH_NO_FAST    // A/B builds only
-        const bool fast = false;
-#else
-        const bool fast = (k >= kb) && (k >= g.kstart+3) && (k <= g.kend-4);
-#endif
-        if constexpr (sizeof(TF) == 4)
-            level(k, std::false_type{}, std::false_type{});       // fp32: one body (127 VGPRs, 3-4 waves per SIMD); four bodies cost it a wave
-        else if (rho_one) { if (fast) level(k, std::true_type{}, std::true_type{});  else level(k, std::false_type{}, std::true_type{}); }
-        else              { if (fast) level(k, std::true_type{}, std::false_type{}); else level(k, std::false_type{}, std::false_type{}); }
+        int k = ks;
+        for (; __builtin_expect(k < kf0, 0); ++k) level(k, false_type{}, rho1_tag, Shift{});
+        if constexpr (decltype(unroll_tag)::value)
+            for (; k + 6 <= kf1; k += 6)
+            {
+                level(k,   true_type{}, rho1_tag, std::integral_constant<int, 0>{});
+                level(k+1, true_type{}, rho1_tag, std::integral_constant<int, 1>{});
+                level(k+2, true_type{}, rho1_tag, std::integral_constant<int, 2>{});
+                level(k+3, true_type{}, rho1_tag, std::integral_constant<int, 3>{});
+                level(k+4, true_type{}, rho1_tag, std::integral_constant<int, 4>{});
+                level(k+5, true_type{}, rho1_tag, std::integral_constant<int, 5>{});
+            }
+        for (; __builtin_expect(k < kf1, 0); ++k) level(k, true_type{}, rho1_tag, Shift{});
+        for (; __builtin_expect(k < ke, 0); ++k) level(k, false_type{}, rho1_tag, Shift{});
+    };
+    if constexpr (sizeof(TF) == 4 && !MHH_MARCH_UNROLL_F32)
+    {   // fp32: one body (127 VGPRs, 3-4 waves per SIMD); more bodies cost it a wave
+        for (int k = ks; k < ke; ++k) level(k, false_type{}, false_type{}, Shift{});
     }
-    if (DSTORE && dsk >= 0 && active)
-    {
-        const int cd = col + dsk*kk;
-        if (DSTORE == 1) { tst(f.ut + cd, dsu); tst(f.vt + cd, dsv); }
-        if (DSTORE <= 2 && dsw_on) tst(f.wt + cd, dsw);
-        if (HAS_S) tst(f.st + cd, dss);
-    }
-#ifdef MHH_MARCH_STAMPS
-    if ((threadIdx.x & 63) == 0) for (int n=0; n<8; ++n) atomicAdd(&g_march_stamps[n], stamp_acc[n]);
-#endif
+    else if (__builtin_expect(rho_one, 1)) chunk(true_type{}, true_type{});
+    else              chunk(false_type{}, false_type{});       // anelastic base state: shifted windows (one interior body)
+    if (DSTORE && dsp && active) tst(const_cast<TF*>(adv(pst, -1)), bo0, dss);
+}
+
+// 2 tPr must not have an all-ones significand (div_known, cell_ops.h); 1/3, 1, 0.7 ... have not
+template<class TF> bool known_divisor_ok(TF d)
+{
+    if (!(d > TF(0)) || !std::isfinite(d) || !std::isnormal(d)) return false;
+    int e; const TF m = std::frexp(d, &e);                          // m in [0.5, 1)
+    return std::nextafter(m, TF(1)) != TF(1);
 }
 
 // mode 0: advec_2i5 + diff_smag2 (the fused pass); 1: advec_2i5 only (p may be null); 2: diff_smag2 only
 template<class TF>
 int march_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, int j0, int j1, hipStream_t st, int mode = 0)
 {
-#ifndef MHH_MARCH_NJ
-#define MHH_MARCH_NJ 4
-#endif
     constexpr int NJ = MHH_MARCH_NJ;
     const GridDev<TF> gd = make_grid<TF>(g);
     MarchFields<TF> mf;
@@ -575,7 +579,13 @@ int march_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* 
     mf.rhoref = cp<TF>(f->rhoref); mf.rhorefh = cp<TF>(f->rhorefh);
     mf.ufb = cp<TF>(f->u_fluxbot); mf.uft = cp<TF>(f->u_fluxtop); mf.vfb = cp<TF>(f->v_fluxbot); mf.vft = cp<TF>(f->v_fluxtop);
     mf.sfb = has_s ? cp<TF>(f->s_fluxbot[0]) : nullptr; mf.sft = has_s ? cp<TF>(f->s_fluxtop[0]) : nullptr;
-    mf.visc = TF(f->visc); mf.svisc = has_s ? TF(f->svisc[0]) : TF(0); mf.tPr = p ? TF(p->tPr) : TF(1); mf.sm = (p && mode != 1) ? p->surface_model : 0;
+    mf.visc = TF(f->visc); mf.svisc = has_s ? TF(f->svisc[0]) : TF(0); mf.sm = (p && mode != 1) ? p->surface_model : 0;
+    mf.dxi = gd.dxi_t; mf.dyi = gd.dyi_t; mf.dxih = TF(0.5)*gd.dxi_t; mf.dyih = TF(0.5)*gd.dyi_t;
+    mf.dxd = gd.dxi_d; mf.dyd = gd.dyi_d; mf.dxd2 = TF(2.)*gd.dxi_d; mf.dyd2 = TF(2.)*gd.dyi_d;
+    mf.dxidxi = gd.dxidxi_d; mf.dyidyi = gd.dyidyi_d;
+    const TF tPr = p ? TF(p->tPr) : TF(1);
+    mf.tPr2 = TF(2.)*tPr; mf.rtPr2 = TF(1.)/mf.tPr2;
+    MHH_REQUIRE(mode == 1 || !has_s || known_divisor_ok(mf.tPr2), "tPr must be a positive normal number whose significand is not all ones");
     const bool buoy = mode == 0 && has_s && p->buoyancy == 2 && p->th_for_N2 == 0;
     mf.threfh = buoy ? cp<TF>(p->threfh) : nullptr; mf.grav = buoy ? TF(p->grav) : TF(0);
 #ifndef MHH_MARCH_KC
@@ -586,22 +596,18 @@ int march_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* 
     const MarchTiling t = make_march_tiling(g, NJ, kc, j0, j1);
     const unsigned nblocks = march_blocks(t);
     // 16-byte LDS-DMA needs 16-byte aligned plane rows; other layouts copy in 4-byte pieces (MHH_MARCH_DMA=4 forces that
-    // form, =0 the register-staged one; same arithmetic in all three)
+    // form; same arithmetic in both)
     constexpr int VEC = 16 / (int)sizeof(TF);
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
     const char* env = getenv("MHH_MARCH_DMA");
     const bool aligned = (g->icells % VEC == 0) && al16(f->u) && al16(f->v) && al16(f->w) && (mode == 1 || al16(f->evisc)) && (!has_s || al16(f->s[0]));
-    const int pb = (env && !strcmp(env, "0")) ? 0 : ((env && !strcmp(env, "4")) || !aligned) ? 4 : 16;
-#define MHH_LAUNCH_MARCH(PBV) do { \
-        if (has_s) hipLaunchKernelGGL((rhs25_march_kernel<TF, NJ, true, PBV>),  dim3(nblocks), dim3(64, NJ), 0, st, gd, mf, t); \
-        else       hipLaunchKernelGGL((rhs25_march_kernel<TF, NJ, false, PBV>), dim3(nblocks), dim3(64, NJ), 0, st, gd, mf, t); } while (0)
-#define MHH_LAUNCH_MARCH1(PBV, A, D) do { \
+    const int pb = ((env && !strcmp(env, "4")) || !aligned) ? 4 : 16;
+#define MHH_LAUNCH_MARCH(PBV, A, D) do { \
         if (has_s) hipLaunchKernelGGL((rhs25_march_kernel<TF, NJ, true, PBV, A, D>),  dim3(nblocks), dim3(64, NJ), 0, st, gd, mf, t); \
         else       hipLaunchKernelGGL((rhs25_march_kernel<TF, NJ, false, PBV, A, D>), dim3(nblocks), dim3(64, NJ), 0, st, gd, mf, t); } while (0)
-    if (mode == 0)      { if (pb == 16) MHH_LAUNCH_MARCH(16); else if (pb == 4) MHH_LAUNCH_MARCH(4); else MHH_LAUNCH_MARCH(0); }
-    else if (mode == 1) { if (pb == 16) MHH_LAUNCH_MARCH1(16, true, false); else MHH_LAUNCH_MARCH1(4, true, false); }      // one operator: LDS-DMA forms only
-    else                { if (pb == 16) MHH_LAUNCH_MARCH1(16, false, true); else MHH_LAUNCH_MARCH1(4, false, true); }
-#undef MHH_LAUNCH_MARCH1
+    if (mode == 0)      { if (pb == 16) MHH_LAUNCH_MARCH(16, true, true);  else MHH_LAUNCH_MARCH(4, true, true); }
+    else if (mode == 1) { if (pb == 16) MHH_LAUNCH_MARCH(16, true, false); else MHH_LAUNCH_MARCH(4, true, false); }
+    else                { if (pb == 16) MHH_LAUNCH_MARCH(16, false, true); else MHH_LAUNCH_MARCH(4, false, true); }
 #undef MHH_LAUNCH_MARCH
     MHH_LAUNCH_CHECK();
     return MHH_OK;
@@ -633,13 +639,3 @@ int mhh_diff_smag2_march(const mhh_grid* g, const mhh_fields* f, const mhh_diff_
     if (g->dtype == MHH_F64) return march_launch<double>(g, f, p, -1, -1, as_stream(stream), 2);
     return march_launch<float>(g, f, p, -1, -1, as_stream(stream), 2);
 }
-
-#ifdef MHH_MARCH_STAMPS
-extern "C" __attribute__((visibility("default"))) int mhh_debug_march_stamps(unsigned long long* out)
-{
-    unsigned long long z[8] = {0,0,0,0,0,0,0,0};
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_march_stamps), sizeof(z)) != hipSuccess) return 1;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_march_stamps), z, sizeof(z)) != hipSuccess) return 1;
-    return 0;
-}
-#endif

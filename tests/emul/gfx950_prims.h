@@ -21,5 +21,13 @@ template<class T> inline void stream_store(T* q, T v) { *q = v; }
 inline unsigned lds_address(void*) { return 0; }
 inline unsigned uniform_u32(unsigned v) { return v; }
 template<int PB> inline void lds_dma_sv(const void*, unsigned, unsigned) {}
+template<int PB> inline void lds_dma_sv2(const void*, unsigned, unsigned, unsigned) {}
+template<class T> inline T sgpr(T x) { return x; }
+inline void sched_fence() {}
+inline void keep_vgpr(unsigned&) {}
+template<class T> inline T gload(const T* b, unsigned o) { return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(b) + o); }
+template<class T> inline T gload_stream(const T* b, unsigned o) { return gload(b, o); }
+template<class T> inline void gstore(T* b, unsigned o, T v) { *reinterpret_cast<T*>(reinterpret_cast<char*>(b) + o) = v; }
+template<class T> inline void gstore_stream(T* b, unsigned o, T v) { gstore(b, o, v); }
 template<class T> inline T uniform_load(const T* table, int idx) { return table[idx]; }
 }

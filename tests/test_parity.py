@@ -565,15 +565,15 @@ def test_grid_beyond_32_bit_cell_indices_is_refused(be):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_rhs25_march_copy_forms_agree(be, dtype):
-    """The three plane-copy forms of k_march.hip (16-byte LDS-DMA, 4-byte LDS-DMA, register-staged) and the cell kernel
-    give the same bits; layouts that are not 16-byte aligned take the 4-byte form by themselves."""
+    """The two plane-copy forms of k_march.hip (16-byte LDS-DMA, 4-byte LDS-DMA) and the cell kernel give the same bits;
+    layouts that are not 16-byte aligned take the 4-byte form by themselves."""
     adv, dif = cm.ADVEC_2I5, cm.DIFF_SMAG2
     for shape in [(70, 10, 12), (17, 9, 8)]:
         g = cm.grid_2nd(*shape, gc=(3, 3, 1), dtype=dtype)
         c = cm.Case(g, nscalars=1)
         p = capi.MhhDiffParams(); p.cs = 0.23; p.tPr = 1./3.; p.surface_model = 1
         out = {}
-        for form in ("default", "4", "0", "cell"):
+        for form in ("default", "4", "cell"):
             d = B.DevCase(be, c); f = d.fields()
             key, val = ("MHH_RHS25_IMPL", "cell") if form == "cell" else ("MHH_MARCH_DMA", form)
             if form != "default":
@@ -589,9 +589,40 @@ def test_rhs25_march_copy_forms_agree(be, dtype):
             finally:
                 os.environ.pop(key, None); os.environ.pop("MHH_ADVEC25_IMPL", None); os.environ.pop("MHH_DIFF22_IMPL", None)
             out[form] = [be.host(x) for x in (d.ut, d.vt, d.wt, d.st[0])]
-        for form in ("4", "0", "cell"):
+        for form in ("4", "cell"):
             for a, b, nm in zip(out["default"], out[form], ("ut", "vt", "wt", "st")):
                 assert same(a, b), (shape, form, nm, cm.ulp_diff(a, b))
+
+
+@pytest.mark.parametrize("rho", ["one", "random"])
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_rhs25_march_tall_columns(be, dtype, rho):
+    """Columns tall enough for the rotated six-level groups of k_march.hip, their remainders and several k-chunks (128
+    levels each), Boussinesq (rho == 1: rotated windows) and anelastic (shifted windows) base states, with and without a
+    scalar, ragged in i and j: the fused pass equals the oracle's operator-by-operator result bit for bit."""
+    adv, dif = cm.ADVEC_2I5, cm.DIFF_SMAG2
+    O = cm.oracle()
+    for shape, ns in [((20, 6, 150), 1), ((66, 5, 31), 0), ((12, 9, 133), 1)]:
+        g = cm.grid_2nd(*shape, gc=(3, 3, 1), dtype=dtype)
+        c = cm.Case(g, nscalars=ns, rho=rho)
+        p = capi.MhhDiffParams(); p.cs = 0.23; p.tPr = 1./3.; p.surface_model = 1
+        d = B.DevCase(be, c); f = d.fields()
+        B.ok(be, be.lib.mhh_rhs_exec(d.G, adv, dif, C.byref(f), C.byref(p), be.stream))
+        got = [be.host(x) for x in (d.ut, d.vt, d.wt)] + [be.host(x) for x in d.st]
+        Gh = g.host_struct()
+        ut, vt, wt = c.ut.copy(), c.vt.copy(), c.wt.copy(); st = [x.copy() for x in c.st]
+        a = (ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.rhoref), ptr(c.rhorefh))
+        O.orc_advec_u(Gh, 25, ptr(ut), *a); O.orc_advec_v(Gh, 25, ptr(vt), *a); O.orc_advec_w(Gh, 25, ptr(wt), *a)
+        for n in range(ns):
+            O.orc_advec_s(Gh, 25, ptr(st[n]), ptr(c.s[n]), *a)
+        v5 = dbl(1e-5)
+        O.orc_smag2_diff_u(Gh, 1, ptr(ut), ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.evisc), ptr(c.u_fluxbot), ptr(c.u_fluxtop), ptr(c.rhoref), ptr(c.rhorefh), v5)
+        O.orc_smag2_diff_v(Gh, 1, ptr(vt), ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.evisc), ptr(c.v_fluxbot), ptr(c.v_fluxtop), ptr(c.rhoref), ptr(c.rhorefh), v5)
+        O.orc_smag2_diff_w(Gh, ptr(wt), ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.evisc), ptr(c.rhoref), ptr(c.rhorefh), v5)
+        for n in range(ns):
+            O.orc_smag2_diff_c(Gh, 1, ptr(st[n]), ptr(c.s[n]), ptr(c.evisc), ptr(c.s_fluxbot), ptr(c.s_fluxtop), ptr(c.rhoref), ptr(c.rhorefh), dbl(1./3.), v5)
+        for a_, b_, nm in zip(got, [ut, vt, wt] + st, ("ut", "vt", "wt", "st")):
+            assert same(a_, b_), (shape, rho, nm, cm.ulp_diff(a_, b_))
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
