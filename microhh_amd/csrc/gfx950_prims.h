@@ -89,10 +89,10 @@ template<int PB> __device__ __forceinline__ void lds_dma_sv2(const void* uniform
     uniform_base = (const void*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(ub >> 32)) << 32) |
                                  (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)ub));
     if constexpr (PB == 16)
-        asm volatile("s_mov_b32 %0, m0\n\ts_add_u32 m0, %3, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+        asm volatile("s_mov_b32 %0, m0\n\ts_add_u32 m0, %3, %4\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                      : "=&s"(m0_saved) : "v"(lane_byte_offset), "s"(uniform_base), "s"(lds_wave_base), "s"(lds_offset) : "memory", "scc");
     else
-        asm volatile("s_mov_b32 %0, m0\n\ts_add_u32 m0, %3, %4\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+        asm volatile("s_mov_b32 %0, m0\n\ts_add_u32 m0, %3, %4\n\ts_nop 2\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
                      : "=&s"(m0_saved) : "v"(lane_byte_offset), "s"(uniform_base), "s"(lds_wave_base), "s"(lds_offset) : "memory", "scc");
 }
 // Pin a wave-uniform value in scalar registers of its own. Kernel arguments arrive by merged s_load_dwordx8/x16, and the
@@ -166,4 +166,6 @@ __device__ __forceinline__ void sched_fence() {}
 // the same thing: without it, values loaded in one loop iteration and first used in the next (the prefetched tendencies)
 // get a compiler-inserted vmcnt(0) at that use -- AFTER the next level's copies have been issued, draining them.
 __device__ __forceinline__ void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_waitcnt(0x0F70); }
+// true if the predicate holds on any lane of the wave (wave-uniform)
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
 }

@@ -248,7 +248,13 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
     // Tendencies are touched once per kernel: their loads and stores carry the non-temporal hint, so that they stream past L2
     // instead of evicting the field planes that neighbouring tiles re-read (512^3: HBM fetch 15.4 -> 14.1 GB per launch, same
     // time; -DMHH_MARCH_NO_NT for A/B runs)
-#ifndef MHH_MARCH_NO_NT
+#if defined(MHH_EXP_NOTEND)     // diagnostic build: no tendency traffic
+    auto tld = [](const TF*, unsigned bo) -> TF { return TF(bo); };
+    auto tst = [](TF* base, unsigned bo, TF v) { if (v == TF(-1.2345e300)) gstore(base, bo, v); };
+#elif defined(MHH_EXP_NOMEM)    // diagnostic build: the arithmetic alone (no copies, no global loads, stores behind a condition that never holds)
+    auto tld = [](const TF*, unsigned bo) -> TF { return TF(bo); };
+    auto tst = [](TF* base, unsigned bo, TF v) { if (v == TF(-1.2345e300)) gstore(base, bo, v); };
+#elif !defined(MHH_MARCH_NO_NT)
     auto tld = [](const TF* base, unsigned bo) -> TF { return gload_stream(base, bo); };
     auto tst = [](TF* base, unsigned bo, TF v) { gstore_stream(base, bo, v); };
 #else
@@ -320,6 +326,7 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
         keep_vgpr(bo0); keep_vgpr(bo1); keep_vgpr(bo2); keep_vgpr(bo3);
         // ---- start moving the next level's planes: k+1 of u, v, s; k+2 of w, evisc; window value k+4 -------------------
         const bool more = (k + 1 < ke);
+#ifndef MHH_EXP_NOMEM
         if (more)
         {
             // more: k+2 <= ke <= kend lies inside the array
@@ -327,11 +334,16 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
             if constexpr (DIF) dma_etile(pe, OE + sl(2, RE)*NETILE);
             if constexpr (HAS_S) dma_tile(ps, OS + sl(1, RS)*NTILE);
         }
+#endif
         // window values of level k+4, read unconditionally (no select, no copy): past the top of the array the plane pointer
         // steps back onto the last plane -- such values only enter faces above the top wall, which are never formed
         const int over = (k + 4 > kmaxp) ? kmaxp - (k + 4) : 0;    // <= 0
+#if !defined(MHH_EXP_NOMEM) && !defined(MHH_EXP_NOCOL)
         const TF nu = gload(adv(pu, over), bo3), nv = gload(adv(pv, over), bo3), nw = gload(adv(pw, over), bo2);
         const TF ns = HAS_S ? gload(adv(ps, over), bo3) : TF(0);
+#else
+        const TF nu = TF(bo3 + over) * TF(1e-3), nv = nu + TF(1), nw = nu - TF(1), ns = nu + TF(2);
+#endif
         if (DSTORE && dsp && active) tst(const_cast<TF*>(adv(pst, -1)), bo0, dss);   // the scalar tendency of level k-1
         dsp = false;
         const TF tcu = tpu, tcv = tpv, tcw = tpw, tcs = tps;      // this level's tendencies (loaded during the previous level)
@@ -407,6 +419,14 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
             Dw = R(rk, etw)*(w0p-w0)*dzi;
         }
 
+#ifdef MHH_EXP_NOMATH          // diagnostic build: the memory traffic alone (copies, loads, stores; one LDS read per plane)
+        if ((FAST || k >= kb) && active)
+        {
+            tst(put, bo0, (TPREF ? tcu : tld(put, bo0)) + uk[0] + ek[0]); tst(pvt, bo0, (TPREF ? tcv : tld(pvt, bo0)) + vk[0]);
+            tst(pwt, bo0, (TPREF ? tcw : tld(pwt, bo0)) + wk[0] + wkp[0]); if constexpr (HAS_S) tst(pst, bo0, (TPREF ? tcs : tld(pst, bo0)) + sk[0]);
+        }
+        if (false)
+#endif
         // ---- update the tendencies of level k ----------------------------------------------------------------
         // (sched_fence between the field sections: the instruction scheduler otherwise hoists every LDS read of a level to
         //  its top and the level needs more than the 256 registers of two waves per SIMD)

@@ -15,6 +15,8 @@ template<bool RAW = false> inline void lds_dma4(const void* gsrc, void* lds_wave
     std::memcpy(static_cast<char*>(lds_wave_base) + lane*4, gsrc, 4);
 }
 inline void wait_vmem() {}
+
+inline bool wave_any(bool) { return true; }
 template<class T> inline T stream_load(const T* q) { return *q; }
 template<class T> inline void stream_store(T* q, T v) { *q = v; }
 #define MHH_RAW_DMA 0
@@ -30,4 +32,5 @@ template<class T> inline T gload_stream(const T* b, unsigned o) { return gload(b
 template<class T> inline void gstore(T* b, unsigned o, T v) { *reinterpret_cast<T*>(reinterpret_cast<char*>(b) + o) = v; }
 template<class T> inline void gstore_stream(T* b, unsigned o, T v) { gstore(b, o, v); }
 template<class T> inline T uniform_load(const T* table, int idx) { return table[idx]; }
+
 }
