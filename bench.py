@@ -37,9 +37,13 @@ WORKLOADS = {
 FP32_RHS_ONLY = ("gabls1_1024", "gabls1_slab8")
 
 
-def cpu_baseline(case, sample=(256, 256, 128), reps=5):
-    """The CPU oracle (port of the reference CPU path, -O3 -march=native, 1 thread) on a bounded sample of the
-    same workload. Reported beside the GPU number; never part of the measured product path."""
+def cpu_baseline(case, sample=(256, 256, 256), reps=3, with_pres=True):
+    """CPU baseline on the GPU box's host cores, ONE thread (the reference CPU path has no intra-rank threading): the
+    reference's own stencil translation units compiled in place (oracle/_ref/libmhhref_perf.so: src/advec_*.cxx,
+    src/diff_*.cxx at -O3 -march=native -DNDEBUG, the reference's flags) for Advec::exec, Diff::exec and calc_strain2,
+    and the oracle port (same flags) for what cannot be built from the reference here: the cyclic fills, N2 + calc_evisc
+    (src/grid.cxx needs netcdf.h) and Pres::exec (fftw3.h; the port's FFT is its own radix-2 code, not FFTW).
+    Reported beside the GPU number; never part of the measured product path."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import common as cm
     from common import ptr, dbl
@@ -50,46 +54,101 @@ def cpu_baseline(case, sample=(256, 256, 128), reps=5):
                 z=(cm.moser_z(kt, cfg["size"][2]) if case == "moser600" else None))
     c = cm.Case(g, nscalars=max(cfg["nscalars"], 0), rho="one", periodic=True)
     O = cm.oracle(perf=True); G = g.host_struct()
+    R = cm.ref(perf=True)                      # None where neither the reference nor its prebuilt library is present
     thref = np.full(g.kcells, 300.)
     n2 = np.zeros(g.shape3); pk = np.zeros((kt, jt, it))
     a = (ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.rhoref), ptr(c.rhorefh))
     adv, dif, sm = cfg["advec"], cfg["diff"], cfg["sm"]
+    ns = cfg["nscalars"]
+    refname = {2: "ref_advec_2", 25: "ref_advec_2i5", 4: "ref_advec_4"}.get(adv)
+    use_ref = R is not None and refname is not None
+    tt = {"ref": 0.0, "port": 0.0}
+
+    def timed(kind, fn, *args):
+        t0 = time.perf_counter(); fn(*args); tt[kind] += time.perf_counter() - t0
 
     def step():
-        for f in [c.u, c.v, c.w] + c.s[:cfg["nscalars"]]:
-            O.orc_boundary_cyclic(G, ptr(f), 2)
+        for f in [c.u, c.v, c.w] + c.s[:ns]:
+            timed("port", O.orc_boundary_cyclic, G, ptr(f), 2)
         if dif == 22:
-            O.orc_smag2_strain2(G, sm, ptr(c.evisc), ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.dudz), ptr(c.dvdz))
-            O.orc_calc_N2(G, ptr(n2), ptr(c.s[0]), ptr(thref), dbl(9.81))
-            O.orc_smag2_evisc(G, sm, ptr(c.evisc), ptr(n2), ptr(c.dbdz), ptr(c.z0m), dbl(0.23), dbl(1./3.))
-        O.orc_advec_u(G, adv, ptr(c.ut), *a); O.orc_advec_v(G, adv, ptr(c.vt), *a); O.orc_advec_w(G, adv, ptr(c.wt), *a)
-        for n in range(cfg["nscalars"]):
-            O.orc_advec_s(G, adv, ptr(c.st[n]), ptr(c.s[n]), *a)
+            if use_ref: timed("ref", R.ref_smag2_strain2, G, sm, ptr(c.evisc), ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.dudz), ptr(c.dvdz))
+            else:       timed("port", O.orc_smag2_strain2, G, sm, ptr(c.evisc), ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.dudz), ptr(c.dvdz))
+            timed("port", O.orc_calc_N2, G, ptr(n2), ptr(c.s[0]), ptr(thref), dbl(9.81))
+            timed("port", O.orc_smag2_evisc, G, sm, ptr(c.evisc), ptr(n2), ptr(c.dbdz), ptr(c.z0m), dbl(0.23), dbl(1./3.))
+            timed("port", O.orc_boundary_cyclic, G, ptr(c.evisc), 2)
+        if use_ref:
+            fn = getattr(R, refname)
+            for comp, t in ((0, c.ut), (1, c.vt), (2, c.wt)):
+                timed("ref", fn, G, comp, ptr(t), None, *a)
+            for n in range(ns):
+                timed("ref", fn, G, 3, ptr(c.st[n]), ptr(c.s[n]), *a)
+        else:
+            timed("port", O.orc_advec_u, G, adv, ptr(c.ut), *a); timed("port", O.orc_advec_v, G, adv, ptr(c.vt), *a); timed("port", O.orc_advec_w, G, adv, ptr(c.wt), *a)
+            for n in range(ns):
+                timed("port", O.orc_advec_s, G, adv, ptr(c.st[n]), ptr(c.s[n]), *a)
         if dif == 22:
-            O.orc_smag2_diff_u(G, sm, ptr(c.ut), ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.evisc), ptr(c.u_fluxbot), ptr(c.u_fluxtop), ptr(c.rhoref), ptr(c.rhorefh), dbl(1e-5))
-            O.orc_smag2_diff_v(G, sm, ptr(c.vt), ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.evisc), ptr(c.v_fluxbot), ptr(c.v_fluxtop), ptr(c.rhoref), ptr(c.rhorefh), dbl(1e-5))
-            O.orc_smag2_diff_w(G, ptr(c.wt), ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.evisc), ptr(c.rhoref), ptr(c.rhorefh), dbl(1e-5))
-            for n in range(cfg["nscalars"]):
-                O.orc_smag2_diff_c(G, sm, ptr(c.st[n]), ptr(c.s[n]), ptr(c.evisc), ptr(c.s_fluxbot), ptr(c.s_fluxtop), ptr(c.rhoref), ptr(c.rhorefh), dbl(1./3.), dbl(1e-5))
+            if use_ref:
+                for comp, t, fb, ft in ((0, c.ut, c.u_fluxbot, c.u_fluxtop), (1, c.vt, c.v_fluxbot, c.v_fluxtop), (2, c.wt, None, None)):
+                    timed("ref", R.ref_smag2_diff_uvw, G, comp, sm, ptr(t), ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.evisc), ptr(fb), ptr(ft), ptr(c.rhoref), ptr(c.rhorefh), dbl(1e-5))
+                for n in range(ns):
+                    timed("ref", R.ref_smag2_diff_c, G, sm, ptr(c.st[n]), ptr(c.s[n]), ptr(c.evisc), ptr(c.s_fluxbot), ptr(c.s_fluxtop), ptr(c.rhoref), ptr(c.rhorefh), dbl(1./3.), dbl(1e-5))
+            else:
+                timed("port", O.orc_smag2_diff_u, G, sm, ptr(c.ut), ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.evisc), ptr(c.u_fluxbot), ptr(c.u_fluxtop), ptr(c.rhoref), ptr(c.rhorefh), dbl(1e-5))
+                timed("port", O.orc_smag2_diff_v, G, sm, ptr(c.vt), ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.evisc), ptr(c.v_fluxbot), ptr(c.v_fluxtop), ptr(c.rhoref), ptr(c.rhorefh), dbl(1e-5))
+                timed("port", O.orc_smag2_diff_w, G, ptr(c.wt), ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.evisc), ptr(c.rhoref), ptr(c.rhorefh), dbl(1e-5))
+                for n in range(ns):
+                    timed("port", O.orc_smag2_diff_c, G, sm, ptr(c.st[n]), ptr(c.s[n]), ptr(c.evisc), ptr(c.s_fluxbot), ptr(c.s_fluxtop), ptr(c.rhoref), ptr(c.rhorefh), dbl(1./3.), dbl(1e-5))
         else:
             o = 2 if dif == 2 else 4
-            O.orc_diff_c(G, o, ptr(c.ut), ptr(c.u), dbl(1e-5)); O.orc_diff_c(G, o, ptr(c.vt), ptr(c.v), dbl(1e-5)); O.orc_diff_w(G, o, ptr(c.wt), ptr(c.w), dbl(1e-5))
-        O.orc_pres_exec(G, cfg["pres"], ptr(c.p), ptr(pk), ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.ut), ptr(c.vt), ptr(c.wt), ptr(c.rhoref), ptr(c.rhorefh), dbl(1.0))
+            if use_ref:
+                fn = getattr(R, "ref_diff_%d" % o)
+                timed("ref", fn, G, 0, ptr(c.ut), ptr(c.u), dbl(1e-5)); timed("ref", fn, G, 0, ptr(c.vt), ptr(c.v), dbl(1e-5)); timed("ref", fn, G, 1, ptr(c.wt), ptr(c.w), dbl(1e-5))
+            else:
+                timed("port", O.orc_diff_c, G, o, ptr(c.ut), ptr(c.u), dbl(1e-5)); timed("port", O.orc_diff_c, G, o, ptr(c.vt), ptr(c.v), dbl(1e-5)); timed("port", O.orc_diff_w, G, o, ptr(c.wt), ptr(c.w), dbl(1e-5))
+        if cfg["pres"] and with_pres:
+            timed("port", O.orc_pres_exec, G, cfg["pres"], ptr(c.p), ptr(pk), ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.ut), ptr(c.vt), ptr(c.wt), ptr(c.rhoref), ptr(c.rhorefh), dbl(1.0))
     step()
     ts = []
+    parts = []
     for _ in range(reps):
+        tt["ref"] = tt["port"] = 0.0
         t0 = time.perf_counter(); step(); ts.append(time.perf_counter() - t0)
-    t = float(np.median(ts))
-    return {"value": it*jt*kt / t, "unit": "grid-cell updates/s", "cores": 1, "kind": "port",
-            "sample": "%s %dx%dx%d sub-domain of the same case, %d reps median, oracle built -O3 -march=native (pres FFT: oracle radix-2, not FFTW); box has %d cores"
+        parts.append((tt["ref"], tt["port"]))
+    k = int(np.argsort(ts)[len(ts)//2])
+    t = float(ts[k])
+    return {"value": it*jt*kt / t, "unit": "grid-cell updates/s", "cores": 1, "kind": "reference" if use_ref else "port",
+            "seconds_per_step": t, "reference_kernels_s": parts[k][0], "port_s": parts[k][1],
+            "sample": ("%s %dx%dx%d (whole grid of this size, same case set-up), %d reps median, 1 thread of %d host cores; "
+                       "Advec::exec + Diff::exec + calc_strain2 = the reference's own translation units (oracle/_ref/libmhhref_perf.so, "
+                       "-O3 -march=native -DNDEBUG); cyclic fills, N2 + calc_evisc and Pres::exec = the oracle port, same flags "
+                       "(pres FFT: the port's radix-2 code, not FFTW)" if use_ref else
+                       "%s %dx%dx%d, %d reps median, 1 thread of %d host cores; the oracle port only (reference library not present)")
                       % (case, it, jt, kt, reps, os.cpu_count() or 0)}
+
+
+def recorded_traffic(workload):
+    """HBM bytes per launch of the dominant kernel from the newest profiles/*_traffic.json that scripts/gpu_traffic.sh wrote for
+    this workload -- only if it was measured on the sources this run was built from (microhh_amd/stamp.py)."""
+    import glob
+    from microhh_amd.stamp import source_stamp
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if d.get("workload") == workload and d.get("stamp") == source_stamp() and d.get("build", "default") == "default":
+            best = (f, d)
+    if best is None:
+        return None, None
+    return float(best[1]["total_bytes"]), os.path.relpath(best[0], ROOT) + " (recorded by rocprofv3 PMC passes on these sources, not measured in this run)"
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="drycblles512", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="time Advec::exec + Diff::exec as separate launches")
@@ -99,9 +158,14 @@ def main():
     ap.add_argument("--share-gpu", action="store_true",
                     help="REHEARSAL of N > 1 on a one-GPU box: every rank runs its HIP kernels on cuda:0, messages go over gloo "
                          "through host copies; never a measurement")
+    ap.add_argument("--build", default="default", choices=["default", "fma"],
+                    help="fma = the second, named build (microhh_amd/libmhh_hip_fma.so: marching kernels with FMA contraction; "
+                         "tolerance stated in tests/test_fma_build.py) instead of the bit-exact default")
     ap.add_argument("--force-slab", action="store_true", help="N=1 only: run the slab code path (halo pack/unpack, split pressure solve) with local copies as exchanges")
     args = ap.parse_args()
 
+    if args.build == "fma":
+        os.environ["MHH_LIB"] = os.path.join(ROOT, "microhh_amd", "libmhh_hip_fma.so")
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -222,11 +286,29 @@ def main():
         "alg_bytes_per_cell_full_step": hp.alg_bytes_rhs() + hp.alg_bytes_visc() + (0 if rhs_only else hp.alg_bytes_pres()),
         "hbm_frac_full_step": (hp.alg_bytes_rhs() + hp.alg_bytes_visc() + (0 if rhs_only else hp.alg_bytes_pres())) * local_cells / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
     }
-    if args.workload == "drycblles512" and world == 1 and not args.unfused:
-        # HBM bytes per launch of this kernel on this workload from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and
-        # WRITE_SIZE in separate runs, FETCH_SIZE doubled for gfx950): profiles/r1j_kernels_pmc.md
-        out["roofline"]["traffic"] = 14.28e9 + 4.70e9               # FETCH_SIZE x 2 + WRITE_SIZE per launch (scripts/gpu_traffic.sh)
-        out["roofline"]["traffic_source"] = "profiles/r1j_kernels_pmc.md"
+    out["build"] = args.build if not os.environ.get("MHH_LIB") or args.build == "fma" else os.path.basename(os.environ["MHH_LIB"])
+    if world == 1 and not args.unfused and out["build"] == "default":
+        out["roofline"]["traffic"], src = recorded_traffic(args.workload)      # FETCH_SIZE x 2 + WRITE_SIZE per launch, or null
+        if src:
+            out["roofline"]["traffic_source"] = src
+    if world == 1 and on_gpu and args.build == "default" and not args.unfused and not rhs_only and not os.environ.get("MHH_LIB") \
+            and os.path.exists(os.path.join(ROOT, "microhh_amd", "libmhh_hip_fma.so")):
+        # the same fused RHS launch from the named FMA build, timed the same way (its own fields; nothing of it enters `value`)
+        from microhh_amd import capi
+        fl = capi.bind(C.CDLL(os.path.join(ROOT, "microhh_amd", "libmhh_hip_fma.so")))
+        hp2 = HotPath(case, itot, jtot, ktot, dtype=np.float64, device="cuda:%d" % local, lib=fl)
+        hp2.cyclic_prognostic(); hp2.exec_viscosity()
+        for _ in range(3):
+            hp2.rhs()
+        ev2 = [(Ev(), Ev()) for _ in range(min(args.steps, 20))]
+        for a_, b_ in ev2:
+            a_.record(); hp2.rhs(); b_.record()
+        torch.cuda.synchronize()
+        fms = float(np.mean([a_.elapsed_time(b_) for a_, b_ in ev2]))
+        out["fma_build"] = {"library": "microhh_amd/libmhh_hip_fma.so", "kernel": "fused RHS (advec+diff) pass", "ms_per_launch": fms,
+                            "frac": alg_bytes / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "tolerance": "tendency increments within 64 ulp of the field's largest increment of the bit-exact build (tests/test_fma_build.py)"}
+        hp2.close()
     if not on_gpu:
         out["data"] = "synthetic; CPU REHEARSAL of the script (emulated kernels, gloo): not a measurement"
     if hp.comm_timing:
@@ -238,7 +320,7 @@ def main():
     if on_gpu and args.share_gpu:
         out["data"] = "synthetic; REHEARSAL of the N > 1 path with all ranks on one GPU (gloo, host-staged messages): not a measurement"
     if rank == 0 and world == 1 and not args.no_cpu_baseline and on_gpu:
-        out["cpu_baseline"] = cpu_baseline("drycblles" if case == "gabls1" else case)
+        out["cpu_baseline"] = cpu_baseline("drycblles" if case == "gabls1" else case, sample=(min(itot, 256), min(jtot, 256), min(ktot, 256)), with_pres=not rhs_only)
     hp.close()
     if dist.is_initialized():
         dist.destroy_process_group()

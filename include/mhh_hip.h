@@ -110,6 +110,9 @@ typedef struct mhh_fields
 
 const char* mhh_last_error(void);
 int mhh_version(void);
+/* Block the host until everything queued on `stream` has finished (NULL = default stream): what the reference's
+ * cudaDeviceSynchronize() at the end of every exec does before Stats reads the tendencies (src/advec_2.cu:219). */
+int mhh_synchronize(void* stream);
 
 /* ---- Boundary_cyclic -------------------------------------------------------------------
  * replaces Boundary_cyclic<TF>::exec_g / exec (src/boundary_cyclic.cu:91-127,

@@ -13,6 +13,7 @@ void Advec_2i4<TF>::exec(Stats<TF>& stats)
     mhh_grid g = mhh_make_grid(grid.get_grid_data(), master.get_MPI_data());
     mhh_fields f = mhh_make_fields(fields);
     mhh_check(mhh_advec_exec(&g, MHH_ADVEC_2I4, &f, /*stream*/ nullptr));
+    mhh_check(mhh_synchronize(nullptr));                      // as cudaDeviceSynchronize() ahead of the statistics, src/advec_2.cu:219
     stats.calc_tend(*fields.mt.at("u"), tend_name);
     stats.calc_tend(*fields.mt.at("v"), tend_name);
     stats.calc_tend(*fields.mt.at("w"), tend_name);

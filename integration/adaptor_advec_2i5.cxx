@@ -19,6 +19,7 @@ void Advec_2i5<TF>::exec(Stats<TF>& stats)
         if (n >= 0) f.s_fluxlimit[n] = 1;
     }
     mhh_check(mhh_advec_exec(&g, MHH_ADVEC_2I5, &f, /*stream*/ nullptr));
+    mhh_check(mhh_synchronize(nullptr));                      // as cudaDeviceSynchronize() ahead of the statistics, src/advec_2.cu:219
     stats.calc_tend(*fields.mt.at("u"), tend_name);
     stats.calc_tend(*fields.mt.at("v"), tend_name);
     stats.calc_tend(*fields.mt.at("w"), tend_name);

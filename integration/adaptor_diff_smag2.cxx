@@ -78,6 +78,7 @@ void Diff_smag2<TF>::exec(Stats<TF>& stats)
     mhh_fields f = mhh_make_fields(fields);
     mhh_diff_params p = make_params<TF>(*this, this->cs, this->tPr, mlen_g, boundary, nullptr, fields, nullptr);
     mhh_check(mhh_diff_exec(&g, MHH_DIFF_SMAG2, &f, &p, nullptr));
+    mhh_check(mhh_synchronize(nullptr));                      // as cudaDeviceSynchronize() ahead of the statistics, src/advec_2.cu:219
     stats.calc_tend(*fields.mt.at("u"), tend_name);
     stats.calc_tend(*fields.mt.at("v"), tend_name);
     stats.calc_tend(*fields.mt.at("w"), tend_name);

@@ -12,6 +12,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["k_stencil.hip", "k_rhs.hip", "k_march.hip", "k_march4.hip", "k_visc.hip", "k_pres.hip", "k_slab.hip"]
 LIB = os.path.join(HERE, "libmhh_hip.so")
+# Second, NAMED build: the marching kernels with FMA contraction allowed (-ffp-contract=fast), everything else the same objects.
+# Not bit-identical to the pinned rounding of the oracle: tests/test_fma_build.py states and checks its tolerance. Selected with
+# MHH_LIB=<this file> (bench.py --build fma); the default library stays the bit-exact one.
+LIB_FMA = os.path.join(HERE, "libmhh_hip_fma.so")
+FMA_SOURCES = ["k_march.hip", "k_march4.hip", "k_visc.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: no FMA contraction, so that every stencil rounds like the reference CPU path built
 # with the same setting (DESIGN.md "Parity").
@@ -49,10 +54,24 @@ def build(force=False, verbose=True):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-    with ThreadPoolExecutor(max_workers=4) as ex:
-        list(ex.map(run, jobs))
+    fma_objs, fma_jobs = [], []
+    fflags = [f for f in CFLAGS if not f.startswith("-ffp-contract")] + ["-ffp-contract=fast", "-DMHH_FMA_BUILD=1"]
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        if s in FMA_SOURCES:
+            obj = os.path.join(CSRC, s.replace(".hip", ".fma.o"))
+            if force or _newer(src, obj) or any(_newer(d, obj) for d in deps):
+                fma_jobs.append([HIPCC] + fflags + ["-c", src, "-o", obj])
+        else:
+            obj = os.path.join(CSRC, s.replace(".hip", ".o"))
+        fma_objs.append(obj)
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        list(ex.map(run, jobs + fma_jobs))
+    link = ["-L/opt/rocm/lib", "-lrocfft", "-Wl,-rpath,/opt/rocm/lib"]
     if jobs or not os.path.exists(LIB):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lrocfft", "-Wl,-rpath,/opt/rocm/lib"])
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + link)
+    if jobs or fma_jobs or not os.path.exists(LIB_FMA):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_FMA] + fma_objs + link)
     return LIB
 
 

@@ -38,6 +38,7 @@ DP = C.POINTER(MhhDiffParams)
 PLAN = vp
 
 SIGNATURES = {
+    "mhh_synchronize": (ci, [vp]),
     "mhh_version": (ci, []),
     "mhh_last_error": (C.c_char_p, []),
     "mhh_reduce_work_bytes": (C.c_ulonglong, []),

@@ -13,6 +13,7 @@
 // bmati[kx]+bmatj[ky]), so results agree to rounding of the transform (DESIGN.md "Parity").
 #include <vector>
 #include <rocfft/rocfft.h>
+#include "fft_lifetime.h"
 #include <cstring>
 #include <cstdlib>
 #include "k_common.h"
@@ -46,7 +47,6 @@ struct mhh_pres_plan
     bool fft_setup = false;
 };
 
-static int g_rocfft_users = 0;
 
 template<class TF> struct C2 { TF x, y; };
 
@@ -186,7 +186,6 @@ MHH_API void mhh_pres_plan_destroy(mhh_pres_plan* P)
     void* bufs[] = {P->cb_data, P->bmati, P->bmatj, P->a, P->c, P->dz, P->rhoref, P->packed, P->spec, P->work, P->fwd_wb, P->bwd_wb,
                     P->m[0], P->m[1], P->m[2], P->m[3], P->m[4], P->m[5], P->m[6]};
     for (void* b : bufs) if (b) (void)hipFree(b);
-    if (P->fft_setup && --g_rocfft_users == 0) rocfft_cleanup();
     delete P;
 }
 
@@ -221,7 +220,7 @@ MHH_API int mhh_pres_plan_create(const mhh_grid* g, int order, const void* host_
     if (!e) { hipError_t h = hipMalloc(&P->work, nwork*P->esz); if (h != hipSuccess) { set_error("hipMalloc work: %s", hipGetErrorString(h)); e = MHH_ENOMEM; } }
     if (!e)
     {
-        if (g_rocfft_users++ == 0) rocfft_setup();
+        fft_acquire();
         P->fft_setup = true;
         e = make_fft(P, true, &P->fwd, &P->fwd_info, &P->fwd_wb);
         if (!e) e = make_fft(P, false, &P->bwd, &P->bwd_info, &P->bwd_wb);

@@ -8,6 +8,7 @@
 // (src/transpose.cxx:170-219) and Pres_2::solve swaps the mode indices (src/pres_2.cxx:297-299).
 #include <vector>
 #include <rocfft/rocfft.h>
+#include "fft_lifetime.h"
 #include "k_common.h"
 
 using namespace mhh;
@@ -185,7 +186,7 @@ MHH_API int mhh_pres_slab_plan_create(const mhh_grid* g, const void* host_dz, co
     alloc(&P->packed, nreal*P->esz); alloc(&P->specx, nx*2*P->esz); alloc(&P->specy, ny*2*P->esz); alloc(&P->work, 2*ny*P->esz);          // pivots w2 and eliminated upper diagonal w3 of every column, factored below
     if (!e)
     {
-        rocfft_setup();
+        fft_acquire();
         const rocfft_array_type R = rocfft_array_type_real, H = rocfft_array_type_hermitian_interleaved, Cx = rocfft_array_type_complex_interleaved;
         const size_t bx = (size_t)g->jmax*g->ktot, by = (size_t)P->nxb*g->ktot;
         e = plan1d(&P->fx, rocfft_transform_type_real_forward, rocfft_placement_notinplace, g->dtype, g->itot, bx, R, H, g->itot, P->nxh, &P->wbs);

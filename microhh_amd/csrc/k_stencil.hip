@@ -18,6 +18,7 @@ using namespace mhh;
 
 MHH_API const char* mhh_last_error(void) { return mhh::g_err; }
 MHH_API int mhh_version(void) { return 100; }
+MHH_API int mhh_synchronize(void* stream) { MHH_HIP_TRY(hipStreamSynchronize(mhh::as_stream(stream))); return MHH_OK; }
 
 // =======================================================================================================
 // Boundary_cyclic (src/boundary_cyclic.cxx:370-443; GPU counterpart src/boundary_cyclic.cu:30-127)
@@ -68,6 +69,7 @@ static int cyclic_launch(const mhh_grid* g, void* const* data, int nf, int edge,
 {
     MHH_REQUIRE(nf >= 1 && nf <= MAXF, "1..8 fields per call");
     MHH_REQUIRE(g->igc <= 8 && g->jgc <= 8, "ghost width <= 8");
+    MHH_REQUIRE(g->imax >= g->igc && (g->jtot == 1 || g->jmax >= g->jgc), "the interior must be at least as wide as the ghost zone it fills (src/grid.cxx:420)");
     FieldList<TF> fl;
     for (int n=0; n<MAXF; ++n) fl.f[n] = mp<TF>(data[n < nf ? n : 0]);
     for (int n=0; n<nf; ++n) MHH_REQUIRE(data[n] != nullptr, "null field");
@@ -104,6 +106,7 @@ MHH_API int mhh_boundary_cyclic(const mhh_grid* g, void* data, int edge, void* s
 MHH_API int mhh_boundary_cyclic_2d(const mhh_grid* g, void* data, void* stream)
 {
     if (int e = check_grid(g)) return e;
+    MHH_REQUIRE(g->npy == 1, "slab-decomposed grid: the north-south ghost rows of a 2-D field come from the neighbour exchange (mhh_halo_pack_rows / mhh_halo_unpack_rows), not from a local wrap");
     void* d[1] = {data};
     // one slice: kcells = 1 and the jtot == 1 branch runs on that slice
     if (g->dtype == MHH_F64) return cyclic_launch<double>(g, d, 1, MHH_EDGE_BOTH, 1, 0, 1, as_stream(stream));

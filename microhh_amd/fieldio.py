@@ -33,14 +33,27 @@ def save_field3d(filename, data, grid, offset=0., rank=0, npy=1, kstart=None, ke
     if npy == 1:
         np.ascontiguousarray(inner).tofile(filename)
         return
+    # The global file must already exist at its full size (prepare_global_file, called by ONE rank ahead of a barrier:
+    # HotPath.save). Nothing here creates, truncates or resizes it -- a rank that did would race the others' writes.
     nbytes = kmax * jtot * g.imax * inner.itemsize
-    if rank == 0 and (not os.path.exists(filename) or os.path.getsize(filename) != nbytes):
-        with open(filename, "wb") as f:
-            f.truncate(nbytes)
+    if not os.path.exists(filename) or os.path.getsize(filename) != nbytes:
+        raise FileNotFoundError("%s must be created at %d bytes (fieldio.prepare_global_file) before the slab ranks write into it" % (filename, nbytes))
     mm = np.memmap(filename, dtype=g.np_dtype, mode="r+", shape=(kmax, jtot, g.imax))
     mm[:, rank*g.jmax:(rank+1)*g.jmax, :] = inner
     mm.flush()
     del mm
+
+
+def prepare_global_file(filename, grid, npy, kstart=None, kend=None):
+    """Create (or re-size) the one global file of a slab-decomposed field at its final size, without touching its contents
+    when the size is already right. ONE rank calls this, then all ranks meet at a barrier, then every rank writes its rows:
+    the collective MPI_File_open + subarray view of the reference (src/field3d_io.cxx) spelled out."""
+    g = grid
+    kmax = (g.kend if kend is None else kend) - (g.kstart if kstart is None else kstart)
+    nbytes = kmax * g.jmax * npy * g.imax * np.dtype(g.np_dtype).itemsize
+    with open(filename, "r+b" if os.path.exists(filename) else "w+b") as f:     # never "wb": that would zero rows already written
+        f.truncate(nbytes)
+    return nbytes
 
 
 def load_field3d(filename, grid, offset=0., rank=0, npy=1, kstart=None, kend=None, out=None):

@@ -75,6 +75,11 @@ class HotPath:
         self._comm_stream = None
         self.device = torch.device(device)
         self.on_gpu = self.device.type == "cuda"
+        if self.on_gpu:
+            # the C ABI allocates plan buffers with hipMalloc on the CURRENT device and launches on a raw stream handle: make
+            # this HotPath's device the current one (cuda:N without a prior torch.cuda.set_device(N) would otherwise put the
+            # plan on device 0 and the fields on device N)
+            torch.cuda.set_device(self.device)
         # Rehearsal of the N > 1 path on a box with fewer GPUs than ranks: several ranks share one card and talk over
         # gloo, which has no device-side send/recv or all-to-all, so the MESSAGES (never the compute) pass through host
         # copies. With the nccl backend (= RCCL, the product path) the device buffers go to the collective as they are.
@@ -446,12 +451,26 @@ class HotPath:
         return names
 
     def save(self, path, iteration=0):
-        """Write the prognostic fields as `name.NNNNNNN`; slab ranks write their rows of the one global file."""
+        """Write the prognostic fields as `name.NNNNNNN`; slab ranks write their rows of the one global file. Rank 0 creates
+        every file at its full size, all ranks meet at a barrier, each writes its rows, and a second barrier ends the call
+        (a reader on another rank then sees complete files)."""
         from . import fieldio
+        names = [(fieldio.field_filename(path, name, iteration), t) for name, t in self._restart_fields()]
         if self.rank == 0:
             fieldio.save_grid(path, self.grid, jtot=self.grid.jmax * self.npy)
-        for name, t in self._restart_fields():
-            fieldio.save_field3d(fieldio.field_filename(path, name, iteration), t.detach().cpu().numpy(), self.grid, rank=self.rank, npy=self.npy)
+            if self.npy > 1:
+                for fn, _ in names:
+                    fieldio.prepare_global_file(fn, self.grid, self.npy)
+        self._barrier()
+        for fn, t in names:
+            fieldio.save_field3d(fn, t.detach().cpu().numpy(), self.grid, rank=self.rank, npy=self.npy)
+        self._barrier()
+
+    def _barrier(self):
+        if self.npy > 1:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                dist.barrier(self.group)
 
     def load(self, path, iteration=0):
         """Read the prognostic fields' interiors back (ghost cells are refreshed by the next cyclic_prognostic())."""

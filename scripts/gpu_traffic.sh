@@ -12,7 +12,7 @@ for v in "" $(ls microhh_amd/variants/*.so 2>/dev/null); do
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$name/$c -- python3 bench.py --workload $WL --steps 2 --warmup 1 --no-cpu-baseline > $OUT/$name.$c.json 2> $OUT/$name.$c.err || { echo "$name $c failed"; tail -2 $OUT/$name.$c.err; }
   done
-  python3 - $OUT/$name "$PAT" "$name" <<'PY'
+  python3 - $OUT/$name "$PAT" "$name" "$WL" <<'PY'
 import csv, glob, sys
 tot = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -22,5 +22,13 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             if sys.argv[2] in r["Kernel_Name"] and r["Counter_Name"] == c: vals.append(float(r["Counter_Value"]))
     tot[c] = sum(vals)/max(1, len(vals))
 print("%-24s fetch %.2f GB  write %.2f GB  total %.2f GB" % (sys.argv[3], tot["FETCH_SIZE"]*2*1024/1e9, tot["WRITE_SIZE"]*1024/1e9, (tot["FETCH_SIZE"]*2 + tot["WRITE_SIZE"])*1024/1e9))
+# the record bench.py reads back (copy it to profiles/<round>_<workload>_traffic.json): bytes per launch + the source stamp
+import json, os
+sys.path.insert(0, os.getcwd())
+from microhh_amd.stamp import source_stamp
+json.dump({"workload": sys.argv[4], "kernel": sys.argv[2], "build": sys.argv[3], "stamp": source_stamp(),
+           "fetch_bytes": tot["FETCH_SIZE"]*2*1024, "write_bytes": tot["WRITE_SIZE"]*1024, "total_bytes": (tot["FETCH_SIZE"]*2 + tot["WRITE_SIZE"])*1024,
+           "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes with --kernel-trace, averages per launch; FETCH_SIZE (KB) doubled for gfx950 (MI355X_MICROARCH.md, HBM); Infinity-Cache hits are counted, not excluded"},
+          open(sys.argv[1] + "_traffic.json", "w"), indent=1)
 PY
 done

@@ -39,11 +39,17 @@ def test_slab_ranks_write_one_global_file(tmp_path):
     whole, parts = str(tmp_path / "u.0000000"), str(tmp_path / "u.0000001")
     fieldio.save_field3d(whole, a, gg)
     npy = 2
-    for r in range(npy):
+    with pytest.raises(FileNotFoundError):            # no rank creates or re-sizes the global file while writing its rows
+        g1 = cm.grid_2nd(12, 8, 6, gc=(3, 3, 1), npy=npy, mpicoordy=1)
+        fieldio.save_field3d(parts, np.zeros(g1.shape3), g1, rank=1, npy=npy)
+    fieldio.prepare_global_file(parts, cm.grid_2nd(12, 8, 6, gc=(3, 3, 1), npy=npy, mpicoordy=0), npy)
+    for r in (1, 0):                                   # any order
         gs = cm.grid_2nd(12, 8, 6, gc=(3, 3, 1), npy=npy, mpicoordy=r)
         loc = np.zeros(gs.shape3)
         loc[:, gs.jstart:gs.jend, :] = a[:, gg.jstart + r*gs.jmax: gg.jstart + (r+1)*gs.jmax, :]
         fieldio.save_field3d(parts, loc, gs, rank=r, npy=npy)
+    assert open(whole, "rb").read() == open(parts, "rb").read()
+    fieldio.prepare_global_file(parts, cm.grid_2nd(12, 8, 6, gc=(3, 3, 1), npy=npy, mpicoordy=0), npy)   # right size already: contents stay
     assert open(whole, "rb").read() == open(parts, "rb").read()
     gs = cm.grid_2nd(12, 8, 6, gc=(3, 3, 1), npy=npy, mpicoordy=1)
     b = fieldio.load_field3d(whole, gs, rank=1, npy=npy)

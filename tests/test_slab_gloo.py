@@ -83,3 +83,35 @@ def test_slab_matches_single_rank(world, slim):
         for p in parts:
             assert float(p["cfl"]) == float(ref["cfl"])
             assert abs(float(p["div"]) - float(ref["div"])) <= 1e-12 * abs(float(ref["div"]))
+
+
+def _save_worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import time
+        lib = B.get("emul").lib
+        hp = HotPath("drycblles", *GRID, device="cpu", lib=lib, npy=world, rank=rank, global_init=synthetic_global("drycblles", *GRID))
+        if rank == 0:
+            time.sleep(0.5)              # rank 0 (which creates the files) arrives LAST: the others must wait for it
+        hp.save(tmp, iteration=3)
+        hp.save(tmp, iteration=3)        # again over existing files of the right size: nobody's rows may be wiped
+        hp.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_slab_ranks_save_restart_files_concurrently():
+    """HotPath.save from two ranks at once (rank 0 creates and sizes every file, barrier, all write, barrier): a
+    stale file of the wrong size is in the way, rank 0 is late, and the result must equal the single-rank files byte for byte."""
+    lib = B.get("emul").lib
+    gi = synthetic_global("drycblles", *GRID)
+    with tempfile.TemporaryDirectory() as one, tempfile.TemporaryDirectory() as two:
+        hp = HotPath("drycblles", *GRID, device="cpu", lib=lib, global_init=gi)
+        hp.save(one, iteration=3); names = [n for n, _ in hp._restart_fields()]; hp.close()
+        with open(os.path.join(two, "u.0000003"), "wb") as f:
+            f.write(b"stale")
+        mp.spawn(_save_worker, args=(2, 29700 + os.getpid() % 1000, two), nprocs=2, join=True)
+        for n in names + ["grid"]:
+            fn = "%s.%07d" % (n, 0 if n == "grid" else 3)
+            assert open(os.path.join(one, fn), "rb").read() == open(os.path.join(two, fn), "rb").read(), fn

@@ -38,21 +38,21 @@ def test_ghost_cells_bitexact(name, dtype):
                 assert np.array_equal(be.host(d), want)
 
 
-def run_tg(be, itot, ktot, T=0.2, dt=0.005):
+def run_tg(be, itot, ktot, T=0.2, dt=0.005, jtot=1):
     cfg = CASES["taylorgreen"]
     nu = cfg["visc"]
     dx, dz = 1./itot, 0.5/ktot
     x, xh = (np.arange(itot)+0.5)*dx, np.arange(itot)*dx
     z, zh = (np.arange(ktot)+0.5)*dz, np.arange(ktot)*dz
-    gi = {"u": (np.sin(2*np.pi*xh)[None, None, :]*np.cos(2*np.pi*z)[:, None, None]) * np.ones((ktot, 1, itot)),
-          "w": (-np.cos(2*np.pi*x)[None, None, :]*np.sin(2*np.pi*zh)[:, None, None]) * np.ones((ktot, 1, itot)),
-          "v": np.zeros((ktot, 1, itot))}
+    gi = {"u": (np.sin(2*np.pi*xh)[None, None, :]*np.cos(2*np.pi*z)[:, None, None]) * np.ones((ktot, jtot, itot)),
+          "w": (-np.cos(2*np.pi*x)[None, None, :]*np.sin(2*np.pi*zh)[:, None, None]) * np.ones((ktot, jtot, itot)),
+          "v": np.zeros((ktot, jtot, itot))}
     for n in ("ut", "vt", "wt"):
-        gi[n] = np.zeros((ktot, 1, itot))
+        gi[n] = np.zeros((ktot, jtot, itot))
     for n in SURF:
-        gi[n] = np.zeros((1, itot))
+        gi[n] = np.zeros((jtot, itot))
     dev = "cuda:0" if be.name == "hip" else "cpu"
-    hp = HotPath("taylorgreen", itot, 1, ktot, device=dev, lib=be.lib, global_init=gi, dt=dt)
+    hp = HotPath("taylorgreen", itot, jtot, ktot, device=dev, lib=be.lib, global_init=gi, dt=dt)
     g = hp.grid
     zero2 = hp.surf["dudz"]                      # zero gradient at both walls (free slip)
     nsteps = int(round(T/dt))
@@ -72,10 +72,16 @@ def run_tg(be, itot, ktot, T=0.2, dt=0.005):
     div = hp.divergence()
     hp.sync()
     it = g.interior
-    u = (hp.u.cpu().numpy() if be.name == "hip" else hp.u.numpy())[it][:, 0, :]
-    w = (hp.w.cpu().numpy() if be.name == "hip" else hp.w.numpy())[it][:, 0, :]
-    p = (hp.p.cpu().numpy() if be.name == "hip" else hp.p.numpy())[it][:, 0, :]
+    u3 = (hp.u.cpu().numpy() if be.name == "hip" else hp.u.numpy())[it]
+    w3 = (hp.w.cpu().numpy() if be.name == "hip" else hp.w.numpy())[it]
+    p3 = (hp.p.cpu().numpy() if be.name == "hip" else hp.p.numpy())[it]
+    v3 = (hp.v.cpu().numpy() if be.name == "hip" else hp.v.numpy())[it]
     hp.close()
+    # the 3-D variant (jtot > 1, uniform in y, src/fields.cxx:995-996): every y-row carries the 2-D solution and v stays zero
+    assert float(np.abs(v3).max()) < 1e-12
+    for a3 in (u3, w3, p3):
+        assert float(np.abs(a3 - a3[:, :1, :]).max()) < 1e-12
+    u, w, p = u3[:, 0, :], w3[:, 0, :], p3[:, 0, :]
     dec = np.exp(-8*np.pi**2*nu*T)
     uref = np.sin(2*np.pi*xh)[None, :]*np.cos(2*np.pi*z)[:, None]*dec
     wref = -np.cos(2*np.pi*x)[None, :]*np.sin(2*np.pi*zh)[:, None]*dec
@@ -94,3 +100,17 @@ def test_taylorgreen_known_answer_and_convergence(name):
         order = np.log2(a/b)
         assert b < 2e-3 and 1.7 < order < 2.4, (n, a, b, order)
     assert e1[3] < 1e-10 and e2[3] < 1e-10        # the projected velocity is divergence free
+
+
+@pytest.mark.gpu
+def test_taylorgreen_3d_64_cubed_configs0():
+    """BASELINE.json configs[0]: taylorgreen 64^3 (jtot = 64, uniform in y), advec_2 + diff_2 + pres_2 + RK3 on the GPU: the same
+    closed form in every y-row, the error of the 64 x 32 two-dimensional run's class, divergence at rounding level."""
+    be = B.get("hip")
+    eu, ew, ep, div = run_tg(be, 64, 64, jtot=64)
+    assert eu < 2e-3 and ew < 2e-3 and ep < 2e-3, (eu, ew, ep)
+    assert div < 1e-10
+    e2 = run_tg(be, 32, 32, jtot=32)
+    for n, a, b in zip("uwp", e2[:3], (eu, ew, ep)):
+        order = np.log2(a/b)
+        assert 1.7 < order < 2.4, (n, a, b, order)
