@@ -119,6 +119,10 @@ int mhh_synchronize(void* stream);
  * src/boundary_cyclic.cxx:370-443) and exec_2d(_g) (:445-500). jtot==1 replicates row. */
 int mhh_boundary_cyclic   (const mhh_grid* g, void* data, int edge, void* stream);
 int mhh_boundary_cyclic_2d(const mhh_grid* g, void* data, void* stream);
+/* Boundary_cyclic::exec(unsigned int*, Edge) / exec_2d(unsigned int*) (src/boundary_cyclic.cxx:510-660): the same fills for
+ * 32-bit integer fields (the immersed-boundary / land-surface index masks), whatever the grid's dtype                    */
+int mhh_boundary_cyclic_u32(const mhh_grid* g, void* data /* unsigned int [ncells] */, int edge, void* stream);
+int mhh_boundary_cyclic_2d_u32(const mhh_grid* g, void* data /* unsigned int [ijcells] */, void* stream);
 /* several fields in one launch (Boundary::set_prognostic_cyclic_bcs, src/boundary.cxx:447-458) */
 int mhh_boundary_cyclic_n (const mhh_grid* g, void* const* data, int nfields, int edge, void* stream);
 

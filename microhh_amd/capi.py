@@ -44,6 +44,8 @@ SIGNATURES = {
     "mhh_reduce_work_bytes": (C.c_ulonglong, []),
     "mhh_boundary_cyclic": (ci, [GP, vp, ci, vp]),
     "mhh_boundary_cyclic_2d": (ci, [GP, vp, vp]),
+    "mhh_boundary_cyclic_u32": (ci, [GP, vp, ci, vp]),
+    "mhh_boundary_cyclic_2d_u32": (ci, [GP, vp, vp]),
     "mhh_boundary_cyclic_n": (ci, [GP, C.POINTER(vp), ci, ci, vp]),
     "mhh_advec_u": (ci, [GP, ci, vp, vp, vp, vp, vp, vp, vp]),
     "mhh_advec_v": (ci, [GP, ci, vp, vp, vp, vp, vp, vp, vp]),

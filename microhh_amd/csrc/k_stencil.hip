@@ -113,6 +113,24 @@ MHH_API int mhh_boundary_cyclic_2d(const mhh_grid* g, void* data, void* stream)
     return cyclic_launch<float>(g, d, 1, MHH_EDGE_BOTH, 1, 0, 1, as_stream(stream));
 }
 
+// the unsigned-int variants: a ghost-cell fill only copies, so a 32-bit integer field is filled as 4-byte values, bit for bit
+// (loads and stores of float registers do not touch the bits, signalling-NaN patterns included)
+MHH_API int mhh_boundary_cyclic_u32(const mhh_grid* g, void* data, int edge, void* stream)
+{
+    if (int e = check_grid(g)) return e;
+    MHH_REQUIRE(edge >= 0 && edge <= 2, "edge");
+    MHH_REQUIRE(g->npy == 1 || edge == MHH_EDGE_EW, "slab-decomposed grid: north-south ghosts come from the neighbour exchange");
+    void* d[1] = {data};
+    return cyclic_launch<float>(g, d, 1, edge, g->kcells, g->kstart, g->kend, as_stream(stream));
+}
+MHH_API int mhh_boundary_cyclic_2d_u32(const mhh_grid* g, void* data, void* stream)
+{
+    if (int e = check_grid(g)) return e;
+    MHH_REQUIRE(g->npy == 1, "slab-decomposed grid: the north-south ghost rows of a 2-D field come from the neighbour exchange");
+    void* d[1] = {data};
+    return cyclic_launch<float>(g, d, 1, MHH_EDGE_BOTH, 1, 0, 1, as_stream(stream));
+}
+
 // =======================================================================================================
 // Advection, one tendency per launch
 // =======================================================================================================

@@ -207,6 +207,9 @@ class Boundary_cyclic
         void exec_g(TF* data, void* stream = nullptr)    { mhh_grid g = grid.abi(); mhh_check(mhh_boundary_cyclic(&g, data, MHH_EDGE_BOTH, stream)); }
         void exec_g(TF* data, Edge e, void* stream = nullptr) { mhh_grid g = grid.abi(); mhh_check(mhh_boundary_cyclic(&g, data, static_cast<int>(e), stream)); }
         void exec_2d_g(TF* data, void* stream = nullptr) { mhh_grid g = grid.abi(); mhh_check(mhh_boundary_cyclic_2d(&g, data, stream)); }
+        // the unsigned int overloads of include/boundary_cyclic.h:46-47 (index masks)
+        void exec_g(unsigned int* data, Edge e = Edge::Both_edges, void* stream = nullptr) { mhh_grid g = grid.abi(); mhh_check(mhh_boundary_cyclic_u32(&g, data, static_cast<int>(e), stream)); }
+        void exec_2d_g(unsigned int* data, void* stream = nullptr) { mhh_grid g = grid.abi(); mhh_check(mhh_boundary_cyclic_2d_u32(&g, data, stream)); }
     private:
         Grid<TF>& grid;
 };

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <iostream>
 #include "../../microhh_amd/host/mhh_host.h"
+#include "../../microhh_amd/host/mhh_host_rccl.h"
 
 using namespace mhh_host;
 typedef double TF;
@@ -28,7 +29,7 @@ int main(int argc, char** argv)
         Grid<TF> grid; auto& gd = grid.gd;
         gd.itot = hdr[0]; gd.jtot = hdr[1]; gd.ktot = hdr[2]; gd.igc = hdr[3]; gd.jgc = hdr[4]; gd.kgc = hdr[5];
         const int sm = hdr[6];
-        const bool fused = hdr[7] & 1, limited = hdr[7] & 2, buoy = hdr[7] & 4;
+        const bool fused = hdr[7] & 1, limited = hdr[7] & 2, buoy = hdr[7] & 4, slab = hdr[7] & 8;
         gd.imax = gd.itot; gd.jmax = gd.jtot; gd.kmax = gd.ktot;
         gd.icells = gd.itot + 2*gd.igc; gd.jcells = gd.jtot + 2*gd.jgc; gd.kcells = gd.ktot + 2*gd.kgc; gd.ijcells = gd.icells*gd.jcells; gd.ncells = gd.ijcells*gd.kcells;
         gd.istart = gd.igc; gd.jstart = gd.jgc; gd.kstart = gd.kgc; gd.iend = gd.istart + gd.itot; gd.jend = gd.jstart + gd.jtot; gd.kend = gd.kstart + gd.ktot;
@@ -78,15 +79,40 @@ int main(int argc, char** argv)
         }
 
         // ---- the slice of Model::exec this package accelerates (src/model.cxx:346-411) ----
-        for (auto& it : fields.mp) boundary_cyclic.exec_g(it.second->fld_g);
-        for (auto& it : fields.sp) boundary_cyclic.exec_g(it.second->fld_g);
-        diff->exec_viscosity(thermo);
-        const double cfl = advec->get_cfl(dt);
-        const double dnum = diff->get_dn(dt);
-        if (fused) diff->exec_with_advec(*advec, stats, nullptr, buoy ? &thermo : nullptr);
-        else     { if (buoy) thermo.exec(grid, fields); advec->exec(stats); diff->exec(stats); }
-        pres->exec(dt, stats);
-        const double div = pres->check_divergence();
+        double cfl, dnum, div;
+        if (!slab)
+        {
+            for (auto& it : fields.mp) boundary_cyclic.exec_g(it.second->fld_g);
+            for (auto& it : fields.sp) boundary_cyclic.exec_g(it.second->fld_g);
+            diff->exec_viscosity(thermo);
+            cfl = advec->get_cfl(dt);
+            dnum = diff->get_dn(dt);
+            if (fused) diff->exec_with_advec(*advec, stats, nullptr, buoy ? &thermo : nullptr);
+            else     { if (buoy) thermo.exec(grid, fields); advec->exec(stats); diff->exec(stats); }
+            pres->exec(dt, stats);
+            div = pres->check_divergence();
+        }
+        else
+        {
+            // the slab code path of a y-decomposed run (mhh_host_rccl.h) on a ONE-rank RCCL communicator: the north-south halos,
+            // both transposes of the pressure solve and the scalar maxima go through ncclSend / ncclRecv / ncclAllReduce to self
+            Master_rccl master;
+            master.init(1, 0, Master_rccl::unique_id(), nullptr);
+            Boundary_cyclic_slab<TF> halo(master, grid);
+            Pres_slab<TF> pres_slab(master, grid, fields);
+            pres_slab.set_reduce_workspace(work);
+            pres_slab.prepare_device();
+            halo.exec_g({fields.mp["u"]->fld_g, fields.mp["v"]->fld_g, fields.mp["w"]->fld_g, fields.sp["th"]->fld_g});   // one message pair for all four
+            diff->exec_viscosity(thermo);
+            cfl = master.max(advec->get_cfl(dt));
+            dnum = master.max(diff->get_dn(dt));
+            if (fused) diff->exec_with_advec(*advec, stats, nullptr, buoy ? &thermo : nullptr);
+            else     { if (buoy) thermo.exec(grid, fields); advec->exec(stats); diff->exec(stats); }
+            pres_slab.exec(dt, stats);
+            div = pres_slab.check_divergence();
+            HIPCHK(hipDeviceSynchronize());
+            pres_slab.clear_device();
+        }
         HIPCHK(hipDeviceSynchronize());
 
         FILE* out = std::fopen(argv[2], "wb");

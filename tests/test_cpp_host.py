@@ -23,10 +23,13 @@ def test_host_header_is_self_contained():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5], ids=["two-calls", "fused", "two-calls-limited", "fused-limited", "two-calls-buoyancy", "fused-buoyancy"])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5, 8, 9], ids=["two-calls", "fused", "two-calls-limited", "fused-limited", "two-calls-buoyancy", "fused-buoyancy",
+                                                              "slab-rccl-two-calls", "slab-rccl-fused"])
 def test_cpp_host_substep_matches_oracle(mode):
     """mode bit 0: advec->exec + diff->exec as the fused pass; bit 1: "th" in advec.fluxlimit_list (kgc = 2);
-    bit 2: Thermo_dry buoyancy (thermo->exec before advec, or folded into the fused pass)."""
+    bit 2: Thermo_dry buoyancy (thermo->exec before advec, or folded into the fused pass); bit 3: the slab code path of
+    microhh_amd/host/mhh_host_rccl.h (north-south halos by ncclSend / ncclRecv, the pressure solve around two grouped all-to-alls,
+    maxima by ncclAllReduce) on a one-rank RCCL communicator -- same oracle, same tolerances."""
     subprocess.run(["make", "-s", "-C", CPP], check=True)
     g = cm.grid_2nd(32, 24, 16, gc=(3, 3, 2 if mode & 2 else 1), stretched=False)
     c = cm.Case(g, rho="one")

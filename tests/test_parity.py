@@ -71,6 +71,27 @@ def test_boundary_cyclic(be, dtype):
         assert same(be.host(d), want)
 
 
+def test_boundary_cyclic_unsigned_int(be):
+    """Boundary_cyclic::exec(unsigned int*) / exec_2d(unsigned int*) (src/boundary_cyclic.cxx:510-660): the integer masks are filled
+    like a field of the same shape -- checked against the oracle's fill of the same bit patterns viewed as float32 (a copy)."""
+    O = cm.oracle()
+    for gd in (np.float64, np.float32):
+        g = cm.grid_2nd(16, 12, 10, gc=(3, 3, 1), dtype=gd)
+        g32 = cm.grid_2nd(16, 12, 10, gc=(3, 3, 1), dtype=np.float32)
+        rs = np.random.RandomState(5)
+        a = rs.randint(0, 2**32, size=g.shape3, dtype=np.uint64).astype(np.uint32)
+        a2 = rs.randint(0, 2**32, size=g.shape2, dtype=np.uint64).astype(np.uint32)
+        for edge in (cm.EDGE_EW, cm.EDGE_NS, cm.EDGE_BOTH):
+            want = a.copy().view(np.float32); O.orc_boundary_cyclic(g32.host_struct(), ptr(want), edge)
+            d = be.arr(a.view(np.int32))
+            B.ok(be, be.lib.mhh_boundary_cyclic_u32(be.grid(g), be.ptr(d), edge, be.stream))
+            assert np.array_equal(be.host(d).view(np.uint32), want.view(np.uint32)) and not np.array_equal(want.view(np.uint32), a)
+        want = a2.copy().view(np.float32); O.orc_boundary_cyclic_2d(g32.host_struct(), ptr(want))
+        d = be.arr(a2.view(np.int32))
+        B.ok(be, be.lib.mhh_boundary_cyclic_2d_u32(be.grid(g), be.ptr(d), be.stream))
+        assert np.array_equal(be.host(d).view(np.uint32), want.view(np.uint32))
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_advec_s_lim_bitexact(be, dtype):
     """Flux-limited scalar advection (include/advec_monotonic.h:79-180): kernel and its place in Advec::exec and the fused RHS."""
