@@ -37,6 +37,65 @@ struct GridDev
 
 MHH_HD double tabs(double a) { return __builtin_fabs(a); }
 MHH_HD float  tabs(float a)  { return __builtin_fabsf(a); }
+
+// ---- F2: TWO single-precision cells per lane (cells i, i+1 of a row). Every operation is the element-wise fp32 operation, so
+// a kernel body written once against its "lane value" type computes, with F2, the same bits per cell as with float -- on
+// gfx950 as packed instructions (v_pk_add_f32, v_pk_mul_f32: two cells per issue slot, no contraction involved). Used by the
+// k-marching kernel for the fp32 configuration (k_march.hip); scalars (metrics, coefficients) stay plain float and broadcast.
+#if defined(__clang__)
+typedef float mhh_f2v __attribute__((ext_vector_type(2)));
+struct F2
+{
+    mhh_f2v v;
+    MHH_HD F2() {}
+    MHH_HD F2(float s) : v{s, s} {}
+    MHH_HD explicit F2(double s) : v{(float)s, (float)s} {}
+    MHH_HD explicit F2(int s) : v{(float)s, (float)s} {}
+    MHH_HD F2(mhh_f2v x) : v(x) {}
+    MHH_HD F2(float a, float b) : v{a, b} {}
+    MHH_HD float lo() const { return v.x; }
+    MHH_HD float hi() const { return v.y; }
+};
+MHH_HD F2 operator+(F2 a, F2 b) { return F2(a.v + b.v); }
+MHH_HD F2 operator-(F2 a, F2 b) { return F2(a.v - b.v); }
+MHH_HD F2 operator*(F2 a, F2 b) { return F2(a.v * b.v); }
+MHH_HD F2 operator/(F2 a, F2 b) { return F2(a.v / b.v); }
+MHH_HD F2 operator-(F2 a) { return F2(-a.v); }
+MHH_HD F2 tabs(F2 a) { return F2(__builtin_elementwise_abs(a.v)); }
+MHH_HD F2 tfma(F2 a, F2 b, F2 c) { return F2(__builtin_fmaf(a.v.x, b.v.x, c.v.x), __builtin_fmaf(a.v.y, b.v.y, c.v.y)); }
+#else   // host compilers (tests/emul): the same type, element by element
+struct F2
+{
+    float v[2];
+    F2() {}
+    F2(float s) : v{s, s} {}
+    explicit F2(double s) : v{(float)s, (float)s} {}
+    explicit F2(int s) : v{(float)s, (float)s} {}
+    F2(float a, float b) : v{a, b} {}
+    float lo() const { return v[0]; }
+    float hi() const { return v[1]; }
+};
+inline F2 operator+(F2 a, F2 b) { return F2(a.v[0] + b.v[0], a.v[1] + b.v[1]); }
+inline F2 operator-(F2 a, F2 b) { return F2(a.v[0] - b.v[0], a.v[1] - b.v[1]); }
+inline F2 operator*(F2 a, F2 b) { return F2(a.v[0] * b.v[0], a.v[1] * b.v[1]); }
+inline F2 operator/(F2 a, F2 b) { return F2(a.v[0] / b.v[0], a.v[1] / b.v[1]); }
+inline F2 operator-(F2 a) { return F2(-a.v[0], -a.v[1]); }
+inline F2 tabs(F2 a) { return F2(__builtin_fabsf(a.v[0]), __builtin_fabsf(a.v[1])); }
+inline F2 tfma(F2 a, F2 b, F2 c) { return F2(__builtin_fmaf(a.v[0], b.v[0], c.v[0]), __builtin_fmaf(a.v[1], b.v[1], c.v[1])); }
+#endif
+MHH_HD F2 operator+(F2 a) { return a; }
+MHH_HD F2 operator+(F2 a, float b) { return a + F2(b); }
+MHH_HD F2 operator+(float a, F2 b) { return F2(a) + b; }
+MHH_HD F2 operator-(F2 a, float b) { return a - F2(b); }
+MHH_HD F2 operator-(float a, F2 b) { return F2(a) - b; }
+MHH_HD F2 operator*(F2 a, float b) { return a * F2(b); }
+MHH_HD F2 operator*(float a, F2 b) { return F2(a) * b; }
+MHH_HD F2 operator/(F2 a, float b) { return a / F2(b); }
+MHH_HD F2& operator+=(F2& a, F2 b) { a = a + b; return a; }
+MHH_HD F2& operator-=(F2& a, F2 b) { a = a - b; return a; }
+// lane-value traits: the scalar type of the arithmetic and the cells a lane carries
+template<class VT> struct lane_of { typedef VT scalar; static constexpr int cells = 1; };
+template<> struct lane_of<F2> { typedef float scalar; static constexpr int cells = 2; };
 template<class TF> MHH_HD TF tmin(TF a, TF b) { return (b < a) ? b : a; }   // std::min semantics
 template<class TF> MHH_HD TF tmax(TF a, TF b) { return (a < b) ? b : a; }   // std::max semantics
 template<class TF> MHH_HD TF sq(TF a) { return a*a; }
@@ -136,8 +195,9 @@ MHH_HD TF advec25_hor(const TF* __restrict__ f, int c, int jj, TF ue, TF uw, TF 
 // LDS plane of row pitch jj). ue/uw/vn/vs may be SUMS a+b of the two velocities a face averages, with dxi/dyi halved by the
 // caller: scaling by 2 commutes with every rounding of the expression (no overflow; exact unless a velocity sum is subnormal),
 // so 0.5*(a+b) * I * dxi and (a+b) * I * (0.5*dxi) are the same bits -- one multiplication per face less.
-template<class TF>
-MHH_HD TF advec25_hor_f0(const TF* __restrict__ f, TF f0, int jj, TF ue, TF uw, TF vn, TF vs, TF dxi, TF dyi)
+// P = something indexable at the cell (a pointer, or the marching kernel's plane view), TF = the lane value, MT = the metrics' type
+template<class P, class TF, class MT>
+MHH_HD TF advec25_hor_f0(const P& f, TF f0, int jj, TF ue, TF uw, TF vn, TF vs, MT dxi, MT dyi)
 {
     const TF fm3 = f[-3], fm2 = f[-2], fm1 = f[-1], fp1 = f[1], fp2 = f[2], fp3 = f[3];
     const TF gm3 = f[-3*jj], gm2 = f[-2*jj], gm1 = f[-jj], gp1 = f[jj], gp2 = f[2*jj], gp3 = f[3*jj];
@@ -157,14 +217,15 @@ MHH_HD TF advec25_hor_f0(const TF* __restrict__ f, TF f0, int jj, TF ue, TF uw, 
 // every x whose residual does not underflow (|x| > 2^-960 in fp64): eddy viscosities are never that small.
 MHH_HD double tfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 MHH_HD float  tfma(float a, float b, float c)    { return __builtin_fmaf(a, b, c); }
-template<class TF>
-MHH_HD TF div_known(TF x, TF d, TF r)
+template<class VT, class TF>
+MHH_HD VT div_known(VT x, TF d, TF r)
 {
-    TF q = x * r;
-    TF e = tfma(-d, q, x);
-    q = tfma(e, r, q);
-    e = tfma(-d, q, x);
-    return tfma(e, r, q);
+    const VT md = VT(-d), rr = VT(r);
+    VT q = x * rr;
+    VT e = tfma(md, q, x);
+    q = tfma(e, rr, q);
+    e = tfma(md, q, x);
+    return tfma(e, rr, q);
 }
 
 // vertical increment (:204-299 etc.) for face orders ot (top) / ob (bottom)

@@ -52,11 +52,11 @@ template<int R, class TF> __device__ __forceinline__ TF win_upw(const TF (&w)[6]
 // vertical advective increment from the face products T = rt*w_t*I_t, B = rb*w_b*I_b, Gt = rt*|w_t|*D_t, Gb likewise
 // x / rc with the wave-uniform shortcut for rc == 1 (Boussinesq base state): x / 1 is x, bit for bit, and an
 // fp64 division is ~12 VALU instructions that this kernel would otherwise issue ~12 times per cell.
-template<class TF> __device__ __forceinline__ TF div_rho(TF x, TF rc, bool one) { return one ? x : x / rc; }
+template<class VT, class TF> __device__ __forceinline__ VT div_rho(VT x, TF rc, bool one) { return one ? x : x / rc; }
 
-template<class TF> __device__ __forceinline__ TF vert_combine(int ot, int ob, TF T, TF B, TF Gt, TF Gb, TF rc, bool one, TF dz)
+template<class VT, class TF> __device__ __forceinline__ VT vert_combine(int ot, int ob, VT T, VT B, VT Gt, VT Gb, TF rc, bool one, TF dz)
 {
-    TF cen;
+    VT cen;
     if (ob == 0)      cen = - div_rho( T, rc, one ) * dz;
     else if (ot == 0) cen = - div_rho( -B, rc, one ) * dz;
     else              cen = - div_rho( T - B, rc, one ) * dz;
@@ -117,15 +117,20 @@ template<int E> __device__ __forceinline__ float scale2(float x)
 //           ds_write); PB = 4: in 4-byte pieces (global_load_lds_dword): any layout, four times the copy instructions.
 // ADV / DIF: which operator's terms are added -- both (the fused pass), or one of them: Advec::exec and Diff::exec as
 // separate calls then run the same kernel body (same bits, same order of accumulation as the fused pass in two steps).
-template<class TF, int NJ, bool HAS_S, int PB, bool ADV = true, bool DIF = true>
-__global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : MHH_MARCH_OCC)) rhs25_march_kernel(const GridDev<TF> g, const MarchFields<TF> f, const MarchTiling mt)
+// VT = the lane value: double or float (one cell per lane), or F2 (two fp32 cells per lane, packed arithmetic: cell_ops.h);
+// TF = its scalar type (metrics, coefficients, the arrays in memory); CW = cells per lane, a wave spans 64*CW cells of a row.
+template<class VT, int NJ, bool HAS_S, int PB, bool ADV = true, bool DIF = true>
+__global__ void __launch_bounds__(64*NJ, (sizeof(VT) == 4 ? MHH_MARCH_OCC_F32 : MHH_MARCH_OCC))
+rhs25_march_kernel(const GridDev<typename lane_of<VT>::scalar> g, const MarchFields<typename lane_of<VT>::scalar> f, const MarchTiling mt)
 {
+    using TF = typename lane_of<VT>::scalar;
+    constexpr int CW = lane_of<VT>::cells;
     static_assert(PB == 16 || PB == 4, "piece size of the LDS-DMA copies");
     constexpr int VEC = 16 / (int)sizeof(TF);                       // elements per 16-byte DMA piece
     constexpr int AL = (PB == 16) ? VEC : 1;                        // granularity of tile widths / origins in elements
-    constexpr int TI = ((70 + AL-1)/AL)*AL;                         // u,v,w,s tile: x from i0-3
+    constexpr int TI = ((64*CW + 6 + AL-1)/AL)*AL;                  // u,v,w,s tile: x from i0-3
     constexpr int EX = (PB == 16) ? VEC : 1;                        // evisc tile: x from i0-EX (aligned for 16-byte DMA)
-    constexpr int TE = ((64 + EX + 1 + AL-1)/AL)*AL;
+    constexpr int TE = ((64*CW + EX + 1 + AL-1)/AL)*AL;
     constexpr int TJ = NJ + 6, TJE = NJ + 2, NT = 64*NJ;
     constexpr int NTILE = TI*TJ, NETILE = TE*TJE;
     // LDS rings, one slot deeper than what a level reads so that the copy of the next plane runs under the whole compute
@@ -139,15 +144,23 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
     if (!decode_march(mt, blockIdx.x, bx, by, kcn)) return;        // whole block leaves together: no barrier hazard
     const int jj = g.icells, kk = g.ijcells;
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty*64 + tx;
-    const int i0 = g.istart + bx*64, j0 = mt.jbase + by*NJ;
+    const int i0 = g.istart + bx*64*CW, j0 = mt.jbase + by*NJ;
     const int kb = g.kstart + kcn*mt.kc;
     const int ke = (kb + mt.kc < g.kend) ? kb + mt.kc : g.kend;
-    const int i = i0 + tx, j = j0 + ty;
+    const int i = i0 + tx*CW, j = j0 + ty;                          // the lane's (first) cell; CW = 2 needs imax even (the launcher checks)
     const bool active = (i < g.iend) && (j < mt.jlim);
-    const int ci = (i < g.iend) ? i : g.iend-1, cj = (j < mt.jlim) ? j : mt.jlim-1;   // clamped column for the window loads
+    const int ci = (i < g.iend) ? i : g.iend-CW, cj = (j < mt.jlim) ? j : mt.jlim-1;   // clamped column for the window loads
     const int col = ci + cj*jj;
     const int ij = col;
-    const int l = (ty+3)*TI + (tx+3), le = (ty+1)*TE + (tx+EX);
+    const int l = (ty+3)*TI + (tx*CW+3), le = (ty+1)*TE + (tx*CW+EX);
+    // a plane in LDS as seen from the lane's cell: [o] = the lane value o cells away (CW = 2: two neighbouring cells, read as two
+    // words -- the compiler assembles the unaligned pairs from aligned 8-byte reads with v_pk_mov_b32)
+    struct LV
+    {
+        const TF* p;
+        __device__ __forceinline__ VT operator[](int o) const { if constexpr (CW == 1) return p[o]; else return VT(p[o], p[o+1]); }
+    };
+    auto ld2d = [&](const TF* q, int c) -> VT { if constexpr (CW == 1) return q[c]; else return VT(q[c], q[c+1]); };   // a 2-D surface array at the lane's column
 
     // interior level of an updating iteration: faces k and k+1 of the centred fields and the w "faces" k-1, k all 6th order
     int kf0 = (kb > g.kstart+3) ? kb : g.kstart+3;                 // first interior level of the chunk
@@ -173,7 +186,7 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
     const TF dxidxi = sgpr(f.dxidxi), dyidyi = sgpr(f.dyidyi);
     const TF visc = sgpr(f.visc), svisc = sgpr(f.svisc), tPr2 = sgpr(f.tPr2), rtPr2 = sgpr(f.rtPr2);
     const TF* __restrict__ tdzi = sgpr(g.dzi); const TF* __restrict__ tdzhi = sgpr(g.dzhi);
-    auto div_tpr = [&](TF x) -> TF { return div_known(x, tPr2, rtPr2); };     // 0.5*x / tPr
+    auto div_tpr = [&](VT x) -> VT { return div_known(x, tPr2, rtPr2); };     // 0.5*x / tPr
 
     // ---- tile movers. A tile is walked in pieces of PW 32-bit words: e = tid + n*NT; piece -> (row, first word) --------
     constexpr int EW = (int)sizeof(TF) / 4;                           // words per element
@@ -248,18 +261,16 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
     // Tendencies are touched once per kernel: their loads and stores carry the non-temporal hint, so that they stream past L2
     // instead of evicting the field planes that neighbouring tiles re-read (512^3: HBM fetch 15.4 -> 14.1 GB per launch, same
     // time; -DMHH_MARCH_NO_NT for A/B runs)
-#if defined(MHH_EXP_NOTEND)     // diagnostic build: no tendency traffic
-    auto tld = [](const TF*, unsigned bo) -> TF { return TF(bo); };
-    auto tst = [](TF* base, unsigned bo, TF v) { if (v == TF(-1.2345e300)) gstore(base, bo, v); };
-#elif defined(MHH_EXP_NOMEM)    // diagnostic build: the arithmetic alone (no copies, no global loads, stores behind a condition that never holds)
-    auto tld = [](const TF*, unsigned bo) -> TF { return TF(bo); };
-    auto tst = [](TF* base, unsigned bo, TF v) { if (v == TF(-1.2345e300)) gstore(base, bo, v); };
+    auto gl = [](const TF* base, unsigned bo) -> VT { if constexpr (CW == 1) return gload(base, bo); else return VT(gload(base, bo), gload(base, bo + 4u)); };
+#if defined(MHH_EXP_NOTEND) || defined(MHH_EXP_NOMEM)   // diagnostic builds (fp64): no tendency traffic / the arithmetic alone (stores behind a condition that never holds)
+    auto tld = [](const TF*, unsigned bo) -> VT { return VT(TF(bo)); };
+    auto tst = [](TF* base, unsigned bo, VT v) { if constexpr (CW == 1) { if (v == TF(-1.2345e300)) gstore(base, bo, v); } };
 #elif !defined(MHH_MARCH_NO_NT)
-    auto tld = [](const TF* base, unsigned bo) -> TF { return gload_stream(base, bo); };
-    auto tst = [](TF* base, unsigned bo, TF v) { gstore_stream(base, bo, v); };
+    auto tld = [](const TF* base, unsigned bo) -> VT { if constexpr (CW == 1) return gload_stream(base, bo); else return VT(gload_stream(base, bo), gload_stream(base, bo + 4u)); };
+    auto tst = [](TF* base, unsigned bo, VT v) { if constexpr (CW == 1) gstore_stream(base, bo, v); else { gstore_stream(base, bo, v.lo()); gstore_stream(base, bo + 4u, v.hi()); } };
 #else
-    auto tld = [](const TF* base, unsigned bo) -> TF { return gload(base, bo); };
-    auto tst = [](TF* base, unsigned bo, TF v) { gstore(base, bo, v); };
+    auto tld = [](const TF* base, unsigned bo) -> VT { if constexpr (CW == 1) return gload(base, bo); else return VT(gload(base, bo), gload(base, bo + 4u)); };
+    auto tst = [](TF* base, unsigned bo, VT v) { if constexpr (CW == 1) gstore(base, bo, v); else { gstore(base, bo, v.lo()); gstore(base, bo + 4u, v.hi()); } };
 #endif
     unsigned bo0 = (unsigned)col * (unsigned)sizeof(TF);              // this column in a plane, one / two / three planes up
     unsigned bo1 = (unsigned)(col + kk) * (unsigned)sizeof(TF), bo2 = (unsigned)(col + 2*kk) * (unsigned)sizeof(TF);
@@ -271,12 +282,12 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
     dma_tile(plane(f.w, ks), OW + slot(ks, RW)*NTILE); dma_tile(plane(f.w, ks+1), OW + slot(ks+1, RW)*NTILE);
     if constexpr (DIF) for (int p = ks-1; p <= ks+1; ++p) dma_etile(plane(f.ev, p), OE + slot(p, RE)*NETILE);
     if constexpr (HAS_S) dma_tile(plane(f.s, ks), OS + slot(ks, RS)*NTILE);
-    TF uw[6], vw[6], ww[6], sw[6];         // levels ks-2 .. ks+3
+    VT uw[6], vw[6], ww[6], sw[6];         // levels ks-2 .. ks+3
 #pragma unroll
     for (int n=0; n<6; ++n)
     {
-        uw[n] = plane(f.u, ks-2+n)[col]; vw[n] = plane(f.v, ks-2+n)[col]; ww[n] = plane(f.w, ks-2+n)[col];
-        sw[n] = HAS_S ? plane(f.s, ks-2+n)[col] : TF(0);
+        uw[n] = ld2d(plane(f.u, ks-2+n), col); vw[n] = ld2d(plane(f.v, ks-2+n), col); ww[n] = ld2d(plane(f.w, ks-2+n), col);
+        sw[n] = HAS_S ? ld2d(plane(f.s, ks-2+n), col) : VT(TF(0));
     }
     // running plane pointers (wave-uniform): at level k, pu / pv / ps point at plane k+1, pw / pe at plane k+2 (the planes
     // to copy; the window values of level k+4 are three / two planes further up), the tendencies' at plane k
@@ -289,8 +300,9 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
 
     // carried bottom-face products: advective centred (T) and upwind (G) parts, diffusive flux (D); the advective ones of
     // u, v, w hold TWICE the reference's face product (the advecting velocity enters as the sum of the two values it averages)
-    TF cTu = 0, cGu = 0, cDu = 0, cTv = 0, cGv = 0, cDv = 0, cTw = 0, cGw = 0, cDw = 0, cTs = 0, cGs = 0, cDs = 0;
-    TF u1m = 0, vNm = 0;                   // u(i+1), v(j+1) of the level below (the w equation's faces)
+    const VT zero = VT(TF(0));
+    VT cTu = zero, cGu = zero, cDu = zero, cTv = zero, cGv = zero, cDv = zero, cTw = zero, cGw = zero, cDw = zero, cTs = zero, cGs = zero, cDs = zero;
+    VT u1m = zero, vNm = zero;             // u(i+1), v(j+1) of the level below (the w equation's faces)
 
     // Latency of the tendency read-modify-writes (fp64 form; the fp32 form has no registers to spare at four waves per SIMD):
     //  * TPREF: the tendencies of the NEXT level are loaded a whole level ahead of their use, like the LDS-DMA planes;
@@ -302,10 +314,10 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
 #ifndef MHH_MARCH_DSTORE
 #define MHH_MARCH_DSTORE 1
 #endif
-    constexpr bool TPREF = (sizeof(TF) == 8) && (MHH_MARCH_TPREF != 0);
-    constexpr bool DSTORE = (sizeof(TF) == 8) && HAS_S && (MHH_MARCH_DSTORE != 0);
-    TF dss = 0; bool dsp = false;          // deferred scalar tendency of the level below
-    TF tpu = 0, tpv = 0, tpw = 0, tps = 0;
+    constexpr bool TPREF = (sizeof(VT) == 8) && (MHH_MARCH_TPREF != 0);
+    constexpr bool DSTORE = (sizeof(VT) == 8) && HAS_S && (MHH_MARCH_DSTORE != 0);
+    VT dss = zero; bool dsp = false;       // deferred scalar tendency of the level below
+    VT tpu = zero, tpv = zero, tpw = zero, tps = zero;
 
     // One level. FAST = an interior level of an updating iteration: every vertical face is 6th/5th order, no wall or
     // surface-flux branch applies -- the face orders and the wall predicates become constants and their dispatch
@@ -317,7 +329,7 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
     {
         constexpr bool FAST = decltype(fast_tag)::value, RHO1 = decltype(rho1_tag)::value;
         constexpr int ROT = decltype(rot_tag)::value, RR = (ROT < 0) ? 0 : ROT;
-        auto R = [](TF r, TF x) { return RHO1 ? x : r*x; };
+        auto R = [](TF r, VT x) -> VT { return RHO1 ? x : r*x; };
         // ring slot of plane k+d: inside a rotated group k - kg0 = ROT (mod 6), a constant for the rings whose depth divides 6
         auto sl = [&](int d, int r) { return (ROT >= 0 && 6 % r == 0) ? (ROT + d + 12) % r : slot(k + d, r); };
         // the lane offsets of the column accesses, re-defined (by nothing) in every level: as loop invariants their zero
@@ -339,30 +351,30 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
         // steps back onto the last plane -- such values only enter faces above the top wall, which are never formed
         const int over = (k + 4 > kmaxp) ? kmaxp - (k + 4) : 0;    // <= 0
 #if !defined(MHH_EXP_NOMEM) && !defined(MHH_EXP_NOCOL)
-        const TF nu = gload(adv(pu, over), bo3), nv = gload(adv(pv, over), bo3), nw = gload(adv(pw, over), bo2);
-        const TF ns = HAS_S ? gload(adv(ps, over), bo3) : TF(0);
+        const VT nu = gl(adv(pu, over), bo3), nv = gl(adv(pv, over), bo3), nw = gl(adv(pw, over), bo2);
+        const VT ns = HAS_S ? gl(adv(ps, over), bo3) : zero;
 #else
-        const TF nu = TF(bo3 + over) * TF(1e-3), nv = nu + TF(1), nw = nu - TF(1), ns = nu + TF(2);
+        const VT nu = VT(TF(bo3 + over) * TF(1e-3)), nv = nu + TF(1), nw = nu - TF(1), ns = nu + TF(2);
 #endif
         if (DSTORE && dsp && active) tst(const_cast<TF*>(adv(pst, -1)), bo0, dss);   // the scalar tendency of level k-1
         dsp = false;
-        const TF tcu = tpu, tcv = tpv, tcw = tpw, tcs = tps;      // this level's tendencies (loaded during the previous level)
+        const VT tcu = tpu, tcv = tpv, tcw = tpw, tcs = tps;      // this level's tendencies (loaded during the previous level)
         if constexpr (TPREF) {             // the warm-up level ks = kb-1 fetches those of kb. Unconditional: inactive lanes sit on
             // a clamped (valid) column and plane k+1 <= kend exists, so no lane mask, no select, no register copy
             tpu = tld(put, bo1); tpv = tld(pvt, bo1); tpw = tld(pwt, bo1); if constexpr (HAS_S) tps = tld(pst, bo1); }
 
-        const TF* __restrict__ uk = L + OU + sl(0, RU)*NTILE + l;
-        const TF* __restrict__ vk = L + OV + sl(0, RU)*NTILE + l;
-        const TF* __restrict__ wk = L + OW + sl(0, RW)*NTILE + l;  const TF* __restrict__ wkp = L + OW + sl(1, RW)*NTILE + l;
-        const TF* __restrict__ sk = L + (HAS_S ? OS + sl(0, RS ? RS : 1)*NTILE + l : 0);
-        const TF* __restrict__ ek = L + (DIF ? OE + sl(0, RE ? RE : 1)*NETILE + le : 0);
-        const TF* __restrict__ ekm = L + (DIF ? OE + sl(-1, RE ? RE : 1)*NETILE + le : 0);
-        const TF* __restrict__ ekp = L + (DIF ? OE + sl(1, RE ? RE : 1)*NETILE + le : 0);
+        const LV uk{L + OU + sl(0, RU)*NTILE + l};
+        const LV vk{L + OV + sl(0, RU)*NTILE + l};
+        const LV wk{L + OW + sl(0, RW)*NTILE + l}, wkp{L + OW + sl(1, RW)*NTILE + l};
+        const LV sk{L + (HAS_S ? OS + sl(0, RS ? RS : 1)*NTILE + l : 0)};
+        const LV ek{L + (DIF ? OE + sl(0, RE ? RE : 1)*NETILE + le : 0)};
+        const LV ekm{L + (DIF ? OE + sl(-1, RE ? RE : 1)*NETILE + le : 0)};
+        const LV ekp{L + (DIF ? OE + sl(1, RE ? RE : 1)*NETILE + le : 0)};
         // the own column at k-1, k, k+1: from the register windows
-        const TF u0m = wv<RR,1>(uw), u0 = wv<RR,2>(uw), u0p = wv<RR,3>(uw);
-        const TF v0m = wv<RR,1>(vw), v0 = wv<RR,2>(vw), v0p = wv<RR,3>(vw);
-        const TF w0 = wv<RR,2>(ww), w0p = wv<RR,3>(ww);
-        const TF s0m = wv<RR,1>(sw), s0 = wv<RR,2>(sw), s0p = wv<RR,3>(sw);
+        const VT u0m = wv<RR,1>(uw), u0 = wv<RR,2>(uw), u0p = wv<RR,3>(uw);
+        const VT v0m = wv<RR,1>(vw), v0 = wv<RR,2>(vw), v0p = wv<RR,3>(vw);
+        const VT w0 = wv<RR,2>(ww), w0p = wv<RR,3>(ww);
+        const VT s0m = wv<RR,1>(sw), s0 = wv<RR,2>(sw), s0p = wv<RR,3>(sw);
         // per-level coefficients: scalar loads (uniform_load), not vector loads whose wait would drain the copies in flight
         const TF rhkp = RHO1 ? TF(1) : uniform_load(f.rhorefh, k+1), rhk = RHO1 ? TF(1) : uniform_load(f.rhorefh, k), rk = RHO1 ? TF(1) : uniform_load(f.rhoref, k);
         const TF dzi = uniform_load(tdzi, k), dzhi = uniform_load(tdzhi, k), dzhip = uniform_load(tdzhi, k+1);
@@ -377,14 +389,14 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
         const bool fb = !FAST && f.sm && (k == g.kstart), ft = !FAST && f.sm && (k == g.kend-1);
         const bool need_dtop = FAST || (!(ft) && (k < g.kend-1 || !f.sm) && (k+1 <= g.kend));   // top diffusive flux of level k is used by k or k+1
 
-        const TF u_e = uk[1], v_n = vk[TI];                      // also next level's u1m, vNm
+        const VT u_e = uk[1], v_n = vk[TI];                      // also next level's u1m, vNm
 
         // ---- top-face quantities of level k --------------------------------------------------------------------
-        TF Tu = 0, Gu = 0, Tv = 0, Gv = 0, Tw = 0, Gw = 0, Ts = 0, Gs = 0;
+        VT Tu = zero, Gu = zero, Tv = zero, Gv = zero, Tw = zero, Gw = zero, Ts = zero, Gs = zero;
         if (ADV && otc != 0)
         {
-            const TF swu = wkp[-1] + w0p;                        // 2 x the advecting w at the u / v point
-            const TF swv = wkp[-TI] + w0p;
+            const VT swu = wkp[-1] + w0p;                        // 2 x the advecting w at the u / v point
+            const VT swv = wkp[-TI] + w0p;
             Tu = R(rhkp, swu) * win_cen<RR>(uw, otc);
             Tv = R(rhkp, swv) * win_cen<RR>(vw, otc);
             if (otc >= 4) { Gu = R(rhkp, tabs(swu)) * win_upw<RR>(uw, otc); Gv = R(rhkp, tabs(swv)) * win_upw<RR>(vw, otc); }
@@ -396,26 +408,26 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
         }
         if (ADV && wlev)
         {
-            const TF sww = w0 + w0p;
+            const VT sww = w0 + w0p;
             Tw = R(rk, sww) * win_cen<RR>(ww, otw);
             if (otw >= 4) Gw = R(rk, tabs(sww)) * win_upw<RR>(ww, otw);
         }
-        TF Du = 0, Dv = 0, Dw = 0, Ds = 0;
+        VT Du = zero, Dv = zero, Dw = zero, Ds = zero;
         if (DIF && need_dtop)
         {
-            const TF etu = TF(0.25)*(ek[-1] + ek[0] + ekp[-1] + ekp[0]) + visc;
+            const VT etu = TF(0.25)*(ek[-1] + ek[0] + ekp[-1] + ekp[0]) + visc;
             Du = R(rhkp, etu)*((u0p-u0)*dzhip + (w0p-wkp[-1])*dxd);
-            const TF etv = TF(0.25)*(ek[-TE] + ek[0] + ekp[-TE] + ekp[0]) + visc;
+            const VT etv = TF(0.25)*(ek[-TE] + ek[0] + ekp[-TE] + ekp[0]) + visc;
             Dv = R(rhkp, etv)*((v0p-v0)*dzhip + (w0p-wkp[-TI])*dyd);
             if (HAS_S)
             {
-                const TF ets = div_tpr(ek[0]+ekp[0]) + svisc;
+                const VT ets = div_tpr(ek[0]+ekp[0]) + svisc;
                 Ds = R(rhkp, ets)*(s0p-s0)*dzhip;
             }
         }
         if (DIF && wlev)
         {
-            const TF etw = ek[0] + visc;
+            const VT etw = ek[0] + visc;
             Dw = R(rk, etw)*(w0p-w0)*dzi;
         }
 
@@ -434,7 +446,7 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
         {
             sched_fence();
             {   // u
-                TF t = TPREF ? tcu : tld(put, bo0);
+                VT t = TPREF ? tcu : tld(put, bo0);
                 if constexpr (ADV)
                 {
                     t += advec25_hor_f0(uk, u0, TI, u0 + u_e, uk[-1] + u0, vk[TI-1] + v_n, vk[-1] + v0, dxih, dyih);
@@ -442,15 +454,15 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
                 }
                 if constexpr (DIF)
                 {
-                    const TF ee = ek[0] + visc, ew = ek[-1] + visc;
-                    const TF en = TF(0.25)*(ek[-1   ] + ek[0  ] + ek[-1+TE] + ek[TE]) + visc;
-                    const TF es = TF(0.25)*(ek[-1-TE] + ek[-TE] + ek[-1   ] + ek[0 ]) + visc;
-                    const TF hor = + ( ee*(u_e-u0)*dxd - ew*(u0-uk[-1])*dxd ) * dxd2
+                    const VT ee = ek[0] + visc, ew = ek[-1] + visc;
+                    const VT en = TF(0.25)*(ek[-1   ] + ek[0  ] + ek[-1+TE] + ek[TE]) + visc;
+                    const VT es = TF(0.25)*(ek[-1-TE] + ek[-TE] + ek[-1   ] + ek[0 ]) + visc;
+                    const VT hor = + ( ee*(u_e-u0)*dxd - ew*(u0-uk[-1])*dxd ) * dxd2
                                    + ( en*((uk[TI]-u0    )*dyd + (v_n-vk[TI-1])*dxd)
                                      - es*((u0    -uk[-TI])*dyd + (v0 -vk[-1  ])*dxd) ) * dyd;
-                    TF ver;
-                    if (fb)      ver = div_rho( Du + rhk * f.ufb[ij], rk, rk1 ) * dzi;
-                    else if (ft) ver = div_rho( - rhkp * f.uft[ij] - cDu, rk, rk1 ) * dzi;
+                    VT ver;
+                    if (fb)      ver = div_rho( Du + rhk * ld2d(f.ufb, ij), rk, rk1 ) * dzi;
+                    else if (ft) ver = div_rho( - rhkp * ld2d(f.uft, ij) - cDu, rk, rk1 ) * dzi;
                     else         ver = div_rho( Du - cDu, rk, rk1 ) * dzi;
                     t += hor + ver;
                 }
@@ -458,7 +470,7 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
             }
             sched_fence();
             {   // v
-                TF t = TPREF ? tcv : tld(pvt, bo0);
+                VT t = TPREF ? tcv : tld(pvt, bo0);
                 if constexpr (ADV)
                 {
                     t += advec25_hor_f0(vk, v0, TI, uk[1-TI] + u_e, uk[-TI] + u0, v0 + v_n, vk[-TI] + v0, dxih, dyih);
@@ -466,15 +478,15 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
                 }
                 if constexpr (DIF)
                 {
-                    const TF ee = TF(0.25)*(ek[-TE  ] + ek[0 ] + ek[1-TE] + ek[1]) + visc;
-                    const TF ew = TF(0.25)*(ek[-1-TE] + ek[-1] + ek[-TE ] + ek[0]) + visc;
-                    const TF en = ek[0] + visc, es = ek[-TE] + visc;
-                    const TF hor = + ( ee*((vk[1]-v0    )*dxd + (u_e-uk[1-TI])*dyd)
+                    const VT ee = TF(0.25)*(ek[-TE  ] + ek[0 ] + ek[1-TE] + ek[1]) + visc;
+                    const VT ew = TF(0.25)*(ek[-1-TE] + ek[-1] + ek[-TE ] + ek[0]) + visc;
+                    const VT en = ek[0] + visc, es = ek[-TE] + visc;
+                    const VT hor = + ( ee*((vk[1]-v0    )*dxd + (u_e-uk[1-TI])*dyd)
                                      - ew*((v0   -vk[-1])*dxd + (u0 -uk[-TI ])*dyd) ) * dxd
                                    + ( en*(v_n-v0)*dyd - es*(v0-vk[-TI])*dyd ) * dyd2;
-                    TF ver;
-                    if (fb)      ver = div_rho( Dv + rhk * f.vfb[ij], rk, rk1 ) * dzi;
-                    else if (ft) ver = div_rho( - rhkp * f.vft[ij] - cDv, rk, rk1 ) * dzi;
+                    VT ver;
+                    if (fb)      ver = div_rho( Dv + rhk * ld2d(f.vfb, ij), rk, rk1 ) * dzi;
+                    else if (ft) ver = div_rho( - rhkp * ld2d(f.vft, ij) - cDv, rk, rk1 ) * dzi;
                     else         ver = div_rho( Dv - cDv, rk, rk1 ) * dzi;
                     t += hor + ver;
                 }
@@ -483,7 +495,7 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
             sched_fence();
             if (FAST || k > g.kstart)
             {   // w
-                TF t = TPREF ? tcw : tld(pwt, bo0);
+                VT t = TPREF ? tcw : tld(pwt, bo0);
                 if (HAS_S && f.threfh) { const TF th_k = uniform_load(f.threfh, k); t += f.grav/th_k * (i2(s0m, s0) - th_k); }   // src/thermo_dry.cxx:165-178
                 if constexpr (ADV)
                 {
@@ -492,10 +504,10 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
                 }
                 if constexpr (DIF)
                 {
-                    const TF ee = TF(0.25)*(ekm[0  ] + ek[0  ] + ekm[1 ] + ek[1 ]) + visc;
-                    const TF ew = TF(0.25)*(ekm[-1 ] + ek[-1 ] + ekm[0 ] + ek[0 ]) + visc;
-                    const TF en = TF(0.25)*(ekm[0  ] + ek[0  ] + ekm[TE] + ek[TE]) + visc;
-                    const TF es = TF(0.25)*(ekm[-TE] + ek[-TE] + ekm[0 ] + ek[0 ]) + visc;
+                    const VT ee = TF(0.25)*(ekm[0  ] + ek[0  ] + ekm[1 ] + ek[1 ]) + visc;
+                    const VT ew = TF(0.25)*(ekm[-1 ] + ek[-1 ] + ekm[0 ] + ek[0 ]) + visc;
+                    const VT en = TF(0.25)*(ekm[0  ] + ek[0  ] + ekm[TE] + ek[TE]) + visc;
+                    const VT es = TF(0.25)*(ekm[-TE] + ek[-TE] + ekm[0 ] + ek[0 ]) + visc;
                     t += + ( ee*((wk[1 ]-w0     )*dxd + (u_e-u1m)*dzhi)
                            - ew*((w0    -wk[-1 ])*dxd + (u0 -u0m)*dzhi) ) * dxd
                          + ( en*((wk[TI]-w0     )*dyd + (v_n-vNm)*dzhi)
@@ -507,7 +519,7 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
             sched_fence();
             if constexpr (HAS_S)
             {   // scalar
-                TF t = TPREF ? tcs : tld(pst, bo0);
+                VT t = TPREF ? tcs : tld(pst, bo0);
                 if constexpr (ADV)
                 {
                     t += advec25_hor_f0(sk, s0, TI, u_e, u0, v_n, v0, dxi, dyi);
@@ -515,16 +527,16 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
                 }
                 if constexpr (DIF)
                 {
-                    const TF e0 = ek[0];
-                    const TF ee = div_tpr(e0     +ek[1 ]) + svisc;
-                    const TF ew = div_tpr(ek[-1 ]+e0    ) + svisc;
-                    const TF en = div_tpr(e0     +ek[TE]) + svisc;
-                    const TF es = div_tpr(ek[-TE]+e0    ) + svisc;
-                    const TF hor = + ( ee*(sk[1 ]-s0) - ew*(s0-sk[-1 ]) ) * dxidxi
+                    const VT e0 = ek[0];
+                    const VT ee = div_tpr(e0     +ek[1 ]) + svisc;
+                    const VT ew = div_tpr(ek[-1 ]+e0    ) + svisc;
+                    const VT en = div_tpr(e0     +ek[TE]) + svisc;
+                    const VT es = div_tpr(ek[-TE]+e0    ) + svisc;
+                    const VT hor = + ( ee*(sk[1 ]-s0) - ew*(s0-sk[-1 ]) ) * dxidxi
                                    + ( en*(sk[TI]-s0) - es*(s0-sk[-TI]) ) * dyidyi;
-                    TF ver;
-                    if (fb)      ver = div_rho( Ds + rhk * f.sfb[ij], rk, rk1 ) * dzi;
-                    else if (ft) ver = div_rho( -rhkp * f.sft[ij] - cDs, rk, rk1 ) * dzi;
+                    VT ver;
+                    if (fb)      ver = div_rho( Ds + rhk * ld2d(f.sfb, ij), rk, rk1 ) * dzi;
+                    else if (ft) ver = div_rho( -rhkp * ld2d(f.sft, ij) - cDs, rk, rk1 ) * dzi;
                     else         ver = div_rho( Ds - cDs, rk, rk1 ) * dzi;
                     t += hor + ver;
                 }
@@ -568,7 +580,7 @@ __global__ void __launch_bounds__(64*NJ, (sizeof(TF) == 4 ? MHH_MARCH_OCC_F32 : 
         for (; __builtin_expect(k < kf1, 0); ++k) level(k, true_type{}, rho1_tag, Shift{});
         for (; __builtin_expect(k < ke, 0); ++k) level(k, false_type{}, rho1_tag, Shift{});
     };
-    if constexpr (sizeof(TF) == 4 && !MHH_MARCH_UNROLL_F32)
+    if constexpr (sizeof(VT) == 4 && !MHH_MARCH_UNROLL_F32)
     {   // fp32: one body (127 VGPRs, 3-4 waves per SIMD); more bodies cost it a wave
         for (int k = ks; k < ke; ++k) level(k, false_type{}, false_type{}, Shift{});
     }
@@ -586,9 +598,12 @@ template<class TF> bool known_divisor_ok(TF d)
 }
 
 // mode 0: advec_2i5 + diff_smag2 (the fused pass); 1: advec_2i5 only (p may be null); 2: diff_smag2 only
-template<class TF>
+// VT = lane value type: double, float, or F2 = two fp32 cells per lane (packed arithmetic; needs an even imax)
+template<class VT>
 int march_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, int j0, int j1, hipStream_t st, int mode = 0)
 {
+    using TF = typename lane_of<VT>::scalar;
+    constexpr int CW = lane_of<VT>::cells;
     constexpr int NJ = MHH_MARCH_NJ;
     const GridDev<TF> gd = make_grid<TF>(g);
     MarchFields<TF> mf;
@@ -613,7 +628,7 @@ int march_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* 
 #endif
     // a strip of a few rows (mhh_rhs_exec_rows on the edge rows) takes short k-chunks: enough blocks to fill the GPU
     const int kc = (j0 >= 0 && (j1 - j0) * 4 <= g->jmax) ? 16 : MHH_MARCH_KC;
-    const MarchTiling t = make_march_tiling(g, NJ, kc, j0, j1);
+    const MarchTiling t = make_march_tiling(g, NJ, kc, j0, j1, 64*CW);
     const unsigned nblocks = march_blocks(t);
     // 16-byte LDS-DMA needs 16-byte aligned plane rows; other layouts copy in 4-byte pieces (MHH_MARCH_DMA=4 forces that
     // form; same arithmetic in both)
@@ -623,8 +638,8 @@ int march_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* 
     const bool aligned = (g->icells % VEC == 0) && al16(f->u) && al16(f->v) && al16(f->w) && (mode == 1 || al16(f->evisc)) && (!has_s || al16(f->s[0]));
     const int pb = ((env && !strcmp(env, "4")) || !aligned) ? 4 : 16;
 #define MHH_LAUNCH_MARCH(PBV, A, D) do { \
-        if (has_s) hipLaunchKernelGGL((rhs25_march_kernel<TF, NJ, true, PBV, A, D>),  dim3(nblocks), dim3(64, NJ), 0, st, gd, mf, t); \
-        else       hipLaunchKernelGGL((rhs25_march_kernel<TF, NJ, false, PBV, A, D>), dim3(nblocks), dim3(64, NJ), 0, st, gd, mf, t); } while (0)
+        if (has_s) hipLaunchKernelGGL((rhs25_march_kernel<VT, NJ, true, PBV, A, D>),  dim3(nblocks), dim3(64, NJ), 0, st, gd, mf, t); \
+        else       hipLaunchKernelGGL((rhs25_march_kernel<VT, NJ, false, PBV, A, D>), dim3(nblocks), dim3(64, NJ), 0, st, gd, mf, t); } while (0)
     if (mode == 0)      { if (pb == 16) MHH_LAUNCH_MARCH(16, true, true);  else MHH_LAUNCH_MARCH(4, true, true); }
     else if (mode == 1) { if (pb == 16) MHH_LAUNCH_MARCH(16, true, false); else MHH_LAUNCH_MARCH(4, true, false); }
     else                { if (pb == 16) MHH_LAUNCH_MARCH(16, false, true); else MHH_LAUNCH_MARCH(4, false, true); }
@@ -634,28 +649,24 @@ int march_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* 
 }
 } // namespace
 
+// fp32: two cells per lane with packed arithmetic where the rows allow it (even imax); MHH_MARCH_F32X2=0 keeps one cell per lane
+static bool f32x2(const mhh_grid* g)
+{
+    const char* e = getenv("MHH_MARCH_F32X2");
+    return g->imax % 2 == 0 && !(e && !strcmp(e, "0"));
+}
+static int march_dispatch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, int j0, int j1, void* stream, int mode)
+{
+    if (g->dtype == MHH_F64) return march_launch<double>(g, f, p, j0, j1, as_stream(stream), mode);
+    if (f32x2(g)) return march_launch<F2>(g, f, p, j0, j1, as_stream(stream), mode);
+    return march_launch<float>(g, f, p, j0, j1, as_stream(stream), mode);
+}
 // entry used by mhh_rhs_exec for the (advec_2i5, diff_smag2) pair: u, v, w and scalar 0 (inputs validated by the caller)
-int mhh_rhs25_march(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, void* stream)
-{
-    if (g->dtype == MHH_F64) return march_launch<double>(g, f, p, -1, -1, as_stream(stream));
-    return march_launch<float>(g, f, p, -1, -1, as_stream(stream));
-}
+int mhh_rhs25_march(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, void* stream) { return march_dispatch(g, f, p, -1, -1, stream, 0); }
 // the same over the rows [j0, j1) only (interior rows while the halos travel, edge rows after: mhh_rhs_exec_rows)
-int mhh_rhs25_march_rows(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, int j0, int j1, void* stream)
-{
-    if (g->dtype == MHH_F64) return march_launch<double>(g, f, p, j0, j1, as_stream(stream));
-    return march_launch<float>(g, f, p, j0, j1, as_stream(stream));
-}
+int mhh_rhs25_march_rows(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, int j0, int j1, void* stream) { return march_dispatch(g, f, p, j0, j1, stream, 0); }
 
 // Advec_2i5::exec / Diff_smag2::exec on their own, for u, v, w and scalar 0 (inputs validated by the caller): the marching
 // kernel with one operator's terms only -- what the two calls of an unfused time step run.
-int mhh_advec25_march(const mhh_grid* g, const mhh_fields* f, void* stream)
-{
-    if (g->dtype == MHH_F64) return march_launch<double>(g, f, nullptr, -1, -1, as_stream(stream), 1);
-    return march_launch<float>(g, f, nullptr, -1, -1, as_stream(stream), 1);
-}
-int mhh_diff_smag2_march(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, void* stream)
-{
-    if (g->dtype == MHH_F64) return march_launch<double>(g, f, p, -1, -1, as_stream(stream), 2);
-    return march_launch<float>(g, f, p, -1, -1, as_stream(stream), 2);
-}
+int mhh_advec25_march(const mhh_grid* g, const mhh_fields* f, void* stream) { return march_dispatch(g, f, nullptr, -1, -1, stream, 1); }
+int mhh_diff_smag2_march(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, void* stream) { return march_dispatch(g, f, p, -1, -1, stream, 2); }

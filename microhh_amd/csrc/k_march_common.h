@@ -30,11 +30,12 @@ __device__ __forceinline__ bool decode_march(const MarchTiling& t, unsigned L, i
 
 // strips of sr tile rows; (strip, k-chunk) units are dealt round-robin to the XCDs; sr shrinks on thin slabs so that all
 // 8 XCDs get work
-inline MarchTiling make_march_tiling(const mhh_grid* g, int NJ, int kc, int j0 = -1, int j1 = -1)
+// tw = cells of a row per tile (a wave's 64 lanes times the cells per lane)
+inline MarchTiling make_march_tiling(const mhh_grid* g, int NJ, int kc, int j0 = -1, int j1 = -1, int tw = 64)
 {
     MarchTiling t;
     t.jbase = (j0 < 0) ? g->jstart : j0; t.jlim = (j1 < 0) ? g->jend : j1;
-    t.nbx = (g->imax + 63)/64; t.nby = (t.jlim - t.jbase + NJ-1)/NJ;
+    t.nbx = (g->imax + tw-1)/tw; t.nby = (t.jlim - t.jbase + NJ-1)/NJ;
     t.kc = kc; t.nkc = (g->kmax + t.kc - 1)/t.kc;
     t.sr = (MHH_STRIP_ROWS + NJ-1)/NJ;
     if (t.sr * 8 > t.nby * t.nkc) t.sr = (t.nby * t.nkc) / 8;

@@ -56,7 +56,7 @@ class HotPath:
     """Device-resident fields of ONE rank + the operator calls of one sub-step."""
 
     def __init__(self, case, itot, jtot, ktot, dtype=np.float64, device="cuda:0", seed=666, dt=1.0,
-                 lib=None, npy=1, rank=0, group=None, global_init=None, force_slab=False, slim_halos=True, overlap=False):
+                 lib=None, npy=1, rank=0, group=None, global_init=None, force_slab=False, slim_halos=True, overlap=None):
         import torch
         self.torch = torch
         self.lib = lib if lib is not None else capi.lib()
@@ -69,9 +69,13 @@ class HotPath:
         # each) and evaluate evisc on the two adjacent ghost rows locally instead of exchanging it
         self.slim = bool(slim_halos)
         # overlap: work the rows that need no north-south halo while the prognostic halos travel on a second stream
-        # (halo_visc_rhs). Opt-in (argument or MHH_OVERLAP=1): the split costs ~0.2 ms of small edge launches per step and what
-        # it hides (~0.4 ms of xGMI time at 512^3 / 8) could not be measured on the one-GPU box of this round.
-        self.overlap = bool(overlap) or os.environ.get("MHH_OVERLAP", "0") == "1"
+        # (halo_visc_rhs). The default with more than one rank (None = auto; MHH_OVERLAP=0 / overlap=False switch it off,
+        # MHH_OVERLAP=1 / overlap=True force it, also on one rank with force_slab): the exchange it hides (25.5 MB each way per
+        # rank at 512^3 / 8) costs more on the wire than the ~0.2 ms of smaller edge launches the split adds.
+        env = os.environ.get("MHH_OVERLAP")
+        if overlap is None:
+            overlap = (npy > 1) if env is None else (env == "1")
+        self.overlap = bool(overlap) or env == "1"
         self._comm_stream = None
         self.device = torch.device(device)
         self.on_gpu = self.device.type == "cuda"

@@ -45,10 +45,10 @@ def test_bench_json_line(world):
 
 
 def test_bench_overlapped_path_two_ranks():
-    d = _run(2, extra=[])                                 # default: overlap off
-    assert d["config"]["halo_overlap"] is False
+    d = _run(2, extra=[])                                 # default with more than one rank: the halo exchange overlaps the interior rows
+    assert d["config"]["halo_overlap"] is True and d["value"] > 0
     env_was = os.environ.get("MHH_OVERLAP")
-    os.environ["MHH_OVERLAP"] = "1"
+    os.environ["MHH_OVERLAP"] = "0"
     try:
         d = _run(2)
     finally:
@@ -56,4 +56,4 @@ def test_bench_overlapped_path_two_ranks():
             os.environ.pop("MHH_OVERLAP", None)
         else:
             os.environ["MHH_OVERLAP"] = env_was
-    assert d["config"]["halo_overlap"] is True and d["value"] > 0
+    assert d["config"]["halo_overlap"] is False and d["value"] > 0
