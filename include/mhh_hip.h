@@ -312,6 +312,20 @@ int mhh_pres_bwd_x_unpack     (mhh_pres_slab_plan* plan, const mhh_grid* g, void
  * mhh_pres_bwd_x_unpack + halo + mhh_pres_output_order, one pass over p, ut, vt, wt less. */
 int mhh_pres_bwd_x_unpack_output(mhh_pres_slab_plan* plan, const mhh_grid* g, void* recvbuf, const mhh_fields* f, void* stream);
 int mhh_pres_output_south_row (const mhh_grid* g, const mhh_fields* f, void* stream);
+/* The same solve in nchunks slices of k (ktot % nchunks == 0), so that the host can overlap the all-to-all of slice c with the
+ * transforms of slice c+1 (the reference's FFT::exec_forward transposes and transforms plane batches in turn as well,
+ * src/fft.cxx:451-583). The all-to-all buffers are then laid out [slice][peer][k in slice][jl][kxl]: slice c is the equal-split
+ * all-to-all of elements [c*n, (c+1)*n), n = mhh_pres_slab_xbuf_elems() / nchunks. Call order per solve:
+ *   for c: fwd_x_pack_chunk(c) -> all-to-all(c);  for c: fwd_y_chunk(c);  solve_y;
+ *   for c: bwd_y_chunk(c) -> all-to-all(c);        for c: bwd_x_chunk(c);  unpack_output_slab; p halo; output_south_row.      */
+int mhh_pres_slab_set_chunks(mhh_pres_slab_plan* plan, int nchunks);          /* 1 = the unsliced calls above */
+int mhh_pres_slab_chunks(const mhh_pres_slab_plan* plan);
+int mhh_pres_fwd_x_pack_chunk(mhh_pres_slab_plan* plan, const mhh_grid* g, void* p_packed, void* sendbuf, int c, void* stream);
+int mhh_pres_fwd_y_chunk     (mhh_pres_slab_plan* plan, const mhh_grid* g, void* recvbuf, int c, void* stream);
+int mhh_pres_solve_y         (mhh_pres_slab_plan* plan, const mhh_grid* g, void* stream);
+int mhh_pres_bwd_y_chunk     (mhh_pres_slab_plan* plan, const mhh_grid* g, void* sendbuf, int c, void* stream);
+int mhh_pres_bwd_x_chunk     (mhh_pres_slab_plan* plan, const mhh_grid* g, void* recvbuf, int c, void* stream);
+int mhh_pres_unpack_output_slab(mhh_pres_slab_plan* plan, const mhh_grid* g, const mhh_fields* f, void* stream);
 
 /* ---- Vertical ghost cells --------------------------------------------------------------
  * Boundary::set_ghost_cells: calc_ghost_cells_{bot,top}_{2nd,4th} (src/boundary.cxx:686-836); bc 0 = Dirichlet

@@ -101,6 +101,14 @@ SIGNATURES = {
     "mhh_pres_bwd_x_unpack": (ci, [PLAN, GP, vp, FP, vp]),
     "mhh_pres_bwd_x_unpack_output": (ci, [PLAN, GP, vp, FP, vp]),
     "mhh_pres_output_south_row": (ci, [GP, FP, vp]),
+    "mhh_pres_slab_set_chunks": (ci, [PLAN, ci]),
+    "mhh_pres_slab_chunks": (ci, [PLAN]),
+    "mhh_pres_fwd_x_pack_chunk": (ci, [PLAN, GP, vp, vp, ci, vp]),
+    "mhh_pres_fwd_y_chunk": (ci, [PLAN, GP, vp, ci, vp]),
+    "mhh_pres_solve_y": (ci, [PLAN, GP, vp]),
+    "mhh_pres_bwd_y_chunk": (ci, [PLAN, GP, vp, ci, vp]),
+    "mhh_pres_bwd_x_chunk": (ci, [PLAN, GP, vp, ci, vp]),
+    "mhh_pres_unpack_output_slab": (ci, [PLAN, GP, FP, vp]),
 }
 
 

@@ -104,8 +104,12 @@ struct mhh_pres_slab_plan
     void* bmati = nullptr; void* bmatj = nullptr; void* a = nullptr; void* c = nullptr; void* dz = nullptr; void* rhoref = nullptr;
     void* packed = nullptr; void* specx = nullptr; void* specy = nullptr; void* work = nullptr;
     rocfft_plan fx = nullptr, bx = nullptr, fy = nullptr, by = nullptr;
+    // the same transforms over ONE k-slice of ktot / nchunks levels (mhh_pres_slab_set_chunks): slice c of the all-to-all can
+    // travel while slice c+1 is transformed
+    int nchunks = 1;
+    rocfft_plan cfx = nullptr, cbx = nullptr, cfy = nullptr, cby = nullptr;
     rocfft_execution_info info = nullptr;
-    void* wb = nullptr; size_t wbs = 0;
+    void* wb = nullptr; size_t wbs = 0, wb_cap = 0;
 };
 
 template<class TF>
@@ -161,7 +165,7 @@ static int plan1d(rocfft_plan* plan, rocfft_transform_type type, rocfft_result_p
 MHH_API void mhh_pres_slab_plan_destroy(mhh_pres_slab_plan* P)
 {
     if (!P) return;
-    for (rocfft_plan p : {P->fx, P->bx, P->fy, P->by}) if (p) rocfft_plan_destroy(p);
+    for (rocfft_plan p : {P->fx, P->bx, P->fy, P->by, P->cfx, P->cbx, P->cfy, P->cby}) if (p) rocfft_plan_destroy(p);
     if (P->info) rocfft_execution_info_destroy(P->info);
     for (void* b : {P->bmati, P->bmatj, P->a, P->c, P->dz, P->rhoref, P->packed, P->specx, P->specy, P->work, P->wb}) if (b) (void)hipFree(b);
     delete P;
@@ -196,7 +200,7 @@ MHH_API int mhh_pres_slab_plan_create(const mhh_grid* g, const void* host_dz, co
         if (!e && rocfft_execution_info_create(&P->info) != rocfft_status_success) { set_error("FFT error: execution_info_create"); e = MHH_EFFT; }
         if (!e && P->wbs)
         {
-            alloc(&P->wb, P->wbs);
+            alloc(&P->wb, P->wbs); P->wb_cap = P->wbs;
             if (!e && rocfft_execution_info_set_work_buffer(P->info, P->wb, P->wbs) != rocfft_status_success) { set_error("FFT error: set_work_buffer"); e = MHH_EFFT; }
         }
     }
@@ -575,6 +579,153 @@ MHH_API int mhh_pres_output_south_row(const mhh_grid* g, const mhh_fields* f, vo
     dim3 grid((g->imax + 255)/256, g->kmax);
 #define CALL(TF) [&]{ const GridDev<TF> gd = make_grid<TF>(g); \
         hipLaunchKernelGGL(pres_out_south_row_kernel<TF>, grid, dim3(256), 0, as_stream(stream), mp<TF>(f->vt), cp<TF>(f->p), gd.dyi_t, g->istart, g->iend, g->jstart, g->kstart, g->icells, g->ijcells); return (int)MHH_OK; }()
+    if (int e = MHH_DISPATCH(g, CALL)) return e;
+#undef CALL
+    MHH_LAUNCH_CHECK();
+    return MHH_OK;
+}
+
+
+// =======================================================================================================
+// The same solve in k-slices (src/fft.cxx:451-583 transforms the planes of a field one k-slice at a time too): the buffers of
+// the all-to-alls are laid out [slice][peer][k in slice][jl][kxl], so that slice c is ONE equal-split all-to-all of its own,
+// which the host issues on a second stream while slice c+1 is being transformed (microhh_amd/model.py: HotPath.pres). Every
+// plane goes through the same transform kernels as in the unsliced call; the Thomas sweeps need all slices.
+// =======================================================================================================
+MHH_API int mhh_pres_slab_set_chunks(mhh_pres_slab_plan* P, int nchunks)
+{
+    MHH_REQUIRE(P && nchunks >= 1 && P->ktot % nchunks == 0, "the number of k-slices must divide ktot");
+    for (rocfft_plan* p : {&P->cfx, &P->cbx, &P->cfy, &P->cby}) if (*p) { rocfft_plan_destroy(*p); *p = nullptr; }
+    P->nchunks = nchunks;
+    if (nchunks == 1) return MHH_OK;
+    const int kc = P->ktot / nchunks;
+    const rocfft_array_type R = rocfft_array_type_real, H = rocfft_array_type_hermitian_interleaved, Cx = rocfft_array_type_complex_interleaved;
+    const size_t bx = (size_t)P->jmax*kc, by = (size_t)P->nxb*kc;
+    size_t wbs = P->wbs;
+    int e = plan1d(&P->cfx, rocfft_transform_type_real_forward, rocfft_placement_notinplace, P->dtype, P->itot, bx, R, H, P->itot, P->nxh, &wbs);
+    if (!e) e = plan1d(&P->cbx, rocfft_transform_type_real_inverse, rocfft_placement_notinplace, P->dtype, P->itot, bx, H, R, P->nxh, P->itot, &wbs);
+    if (!e) e = plan1d(&P->cfy, rocfft_transform_type_complex_forward, rocfft_placement_inplace, P->dtype, P->jtot, by, Cx, Cx, P->jtot, P->jtot, &wbs);
+    if (!e) e = plan1d(&P->cby, rocfft_transform_type_complex_inverse, rocfft_placement_inplace, P->dtype, P->jtot, by, Cx, Cx, P->jtot, P->jtot, &wbs);
+    if (!e && wbs > P->wb_cap)
+    {
+        MHH_HIP_TRY(hipStreamSynchronize(0));          // (the work buffer may still be in use by a solve in flight on the default stream)
+        if (P->wb) (void)hipFree(P->wb);
+        MHH_HIP_TRY(hipMalloc(&P->wb, wbs)); P->wb_cap = wbs;
+        MHH_FFT_TRY(rocfft_execution_info_set_work_buffer(P->info, P->wb, wbs));
+    }
+    P->wbs = wbs;
+    return e;
+}
+MHH_API int mhh_pres_slab_chunks(const mhh_pres_slab_plan* P) { return P ? P->nchunks : 0; }
+
+namespace
+{
+struct Slice { int kc; size_t xseg, sx, sy, pk; };      // levels per slice; element offsets of slice c in xbuf / specx / specy / packed
+inline Slice slice_of(const mhh_pres_slab_plan* P, int c)
+{
+    const int kc = P->ktot / P->nchunks;
+    return Slice{kc, (size_t)c*P->npy*kc*P->jmax*P->nxb, (size_t)c*kc*P->jmax*P->nxh, (size_t)c*kc*P->nxb*P->jtot, (size_t)c*kc*P->jmax*P->itot};
+}
+inline int chunk_ok(const mhh_pres_slab_plan* P, const mhh_grid* g, int c)
+{
+    if (int e = slab_match(P, g)) return e;
+    MHH_REQUIRE(P->nchunks > 1 && c >= 0 && c < P->nchunks, "k-slice index (call mhh_pres_slab_set_chunks first)");
+    return MHH_OK;
+}
+}
+// slice c: x transform of the packed divergence + pack into segment c of sendbuf
+MHH_API int mhh_pres_fwd_x_pack_chunk(mhh_pres_slab_plan* P, const mhh_grid* g, void* p_packed, void* sendbuf, int c, void* stream)
+{
+    if (int e = chunk_ok(P, g, c)) return e;
+    MHH_REQUIRE(sendbuf != nullptr, "sendbuf");
+    if (!p_packed) p_packed = P->packed;
+    const Slice sl = slice_of(P, c);
+    hipStream_t st = as_stream(stream);
+    MHH_FFT_TRY(rocfft_execution_info_set_stream(P->info, st));
+    void* in[1] = {static_cast<char*>(p_packed) + sl.pk*P->esz}; void* out[1] = {static_cast<char*>(P->specx) + sl.sx*2*P->esz};
+    MHH_FFT_TRY(rocfft_execute(P->cfx, in, out, P->info));
+    dim3 grid((P->npy*P->nxb + 255)/256, P->jmax, sl.kc);
+    if (g->dtype == MHH_F64) hipLaunchKernelGGL((xbuf_x_kernel<double, true>), grid, dim3(256), 0, st, (C2<double>*)P->specx + sl.sx, (C2<double>*)sendbuf + sl.xseg, P->nxh, P->nxb, P->jmax, sl.kc, P->npy);
+    else                     hipLaunchKernelGGL((xbuf_x_kernel<float, true>), grid, dim3(256), 0, st, (C2<float>*)P->specx + sl.sx, (C2<float>*)sendbuf + sl.xseg, P->nxh, P->nxb, P->jmax, sl.kc, P->npy);
+    MHH_LAUNCH_CHECK();
+    return MHH_OK;
+}
+// slice c, after its forward all-to-all: reorder into [k][kxl][j] and forward y transform
+MHH_API int mhh_pres_fwd_y_chunk(mhh_pres_slab_plan* P, const mhh_grid* g, void* recvbuf, int c, void* stream)
+{
+    if (int e = chunk_ok(P, g, c)) return e;
+    MHH_REQUIRE(recvbuf != nullptr, "recvbuf");
+    const Slice sl = slice_of(P, c);
+    hipStream_t st = as_stream(stream);
+    MHH_FFT_TRY(rocfft_execution_info_set_stream(P->info, st));
+    dim3 gy((unsigned)(((P->nxb + 31)/32) * ((P->jmax + 63)/64) * P->npy), sl.kc);
+    void* io[1] = {static_cast<char*>(P->specy) + sl.sy*2*P->esz};
+    if (g->dtype == MHH_F64) hipLaunchKernelGGL((xbuf_y_kernel<double, true>), gy, dim3(256), 0, st, (C2<double>*)P->specy + sl.sy, (C2<double>*)recvbuf + sl.xseg, P->nxb, P->jmax, P->jtot, sl.kc);
+    else                     hipLaunchKernelGGL((xbuf_y_kernel<float, true>), gy, dim3(256), 0, st, (C2<float>*)P->specy + sl.sy, (C2<float>*)recvbuf + sl.xseg, P->nxb, P->jmax, P->jtot, sl.kc);
+    MHH_LAUNCH_CHECK();
+    MHH_FFT_TRY(rocfft_execute(P->cfy, io, nullptr, P->info));
+    return MHH_OK;
+}
+// all slices in: the tridiagonal solves over k
+MHH_API int mhh_pres_solve_y(mhh_pres_slab_plan* P, const mhh_grid* g, void* stream)
+{
+    if (int e = slab_match(P, g)) return e;
+    hipStream_t st = as_stream(stream);
+    dim3 gs((2*P->jtot + 127)/128, P->nxb);
+    if (g->dtype == MHH_F64)
+        hipLaunchKernelGGL(tdma_slab_kernel<double>, gs, dim3(128), 0, st, (double*)P->specy, cp<double>(P->work), cp<double>(P->work) + (size_t)P->nxb*P->jtot*P->ktot,
+                           cp<double>(P->a), cp<double>(P->dz), P->nxh, P->nxb, P->rank*P->nxb, P->jtot, P->ktot);
+    else
+        hipLaunchKernelGGL(tdma_slab_kernel<float>, gs, dim3(128), 0, st, (float*)P->specy, cp<float>(P->work), cp<float>(P->work) + (size_t)P->nxb*P->jtot*P->ktot,
+                           cp<float>(P->a), cp<float>(P->dz), P->nxh, P->nxb, P->rank*P->nxb, P->jtot, P->ktot);
+    MHH_LAUNCH_CHECK();
+    return MHH_OK;
+}
+// slice c: inverse y transform + reorder into segment c of sendbuf
+MHH_API int mhh_pres_bwd_y_chunk(mhh_pres_slab_plan* P, const mhh_grid* g, void* sendbuf, int c, void* stream)
+{
+    if (int e = chunk_ok(P, g, c)) return e;
+    MHH_REQUIRE(sendbuf != nullptr, "sendbuf");
+    const Slice sl = slice_of(P, c);
+    hipStream_t st = as_stream(stream);
+    MHH_FFT_TRY(rocfft_execution_info_set_stream(P->info, st));
+    dim3 gy((unsigned)(((P->nxb + 31)/32) * ((P->jmax + 63)/64) * P->npy), sl.kc);
+    void* io[1] = {static_cast<char*>(P->specy) + sl.sy*2*P->esz};
+    MHH_FFT_TRY(rocfft_execute(P->cby, io, nullptr, P->info));
+    if (g->dtype == MHH_F64) hipLaunchKernelGGL((xbuf_y_kernel<double, false>), gy, dim3(256), 0, st, (C2<double>*)P->specy + sl.sy, (C2<double>*)sendbuf + sl.xseg, P->nxb, P->jmax, P->jtot, sl.kc);
+    else                     hipLaunchKernelGGL((xbuf_y_kernel<float, false>), gy, dim3(256), 0, st, (C2<float>*)P->specy + sl.sy, (C2<float>*)sendbuf + sl.xseg, P->nxb, P->jmax, P->jtot, sl.kc);
+    MHH_LAUNCH_CHECK();
+    return MHH_OK;
+}
+// slice c, after its backward all-to-all: back into [k][jl][kx] and inverse x transform into the packed solution
+MHH_API int mhh_pres_bwd_x_chunk(mhh_pres_slab_plan* P, const mhh_grid* g, void* recvbuf, int c, void* stream)
+{
+    if (int e = chunk_ok(P, g, c)) return e;
+    MHH_REQUIRE(recvbuf != nullptr, "recvbuf");
+    const Slice sl = slice_of(P, c);
+    hipStream_t st = as_stream(stream);
+    MHH_FFT_TRY(rocfft_execution_info_set_stream(P->info, st));
+    dim3 grid((P->npy*P->nxb + 255)/256, P->jmax, sl.kc);
+    if (g->dtype == MHH_F64) hipLaunchKernelGGL((xbuf_x_kernel<double, false>), grid, dim3(256), 0, st, (C2<double>*)P->specx + sl.sx, (C2<double>*)recvbuf + sl.xseg, P->nxh, P->nxb, P->jmax, sl.kc, P->npy);
+    else                     hipLaunchKernelGGL((xbuf_x_kernel<float, false>), grid, dim3(256), 0, st, (C2<float>*)P->specx + sl.sx, (C2<float>*)recvbuf + sl.xseg, P->nxh, P->nxb, P->jmax, sl.kc, P->npy);
+    MHH_LAUNCH_CHECK();
+    void* in[1] = {static_cast<char*>(P->specx) + sl.sx*2*P->esz}; void* out[1] = {static_cast<char*>(P->packed) + sl.pk*P->esz};
+    MHH_FFT_TRY(rocfft_execute(P->cbx, in, out, P->info));
+    return MHH_OK;
+}
+// all slices back: unpack + Pres_2::output in one kernel (the tail of mhh_pres_bwd_x_unpack_output)
+MHH_API int mhh_pres_unpack_output_slab(mhh_pres_slab_plan* P, const mhh_grid* g, const mhh_fields* f, void* stream)
+{
+    if (int e = slab_match(P, g)) return e;
+    MHH_REQUIRE(f && f->p && f->ut && f->vt && f->wt, "buffers");
+    hipStream_t st = as_stream(stream);
+    dim3 ug((g->icells + 255)/256, g->jmax, g->kmax + 1);
+    const bool pow2 = is_pow2(g->itot) && is_pow2(g->jtot);
+#define CALL(TF) [&]{ const GridDev<TF> gd = make_grid<TF>(g); \
+        if (pow2) hipLaunchKernelGGL((unpack_out_slab_kernel<true, TF>), ug, dim3(256), 0, st, mp<TF>(f->p), cp<TF>(P->packed), mp<TF>(f->ut), mp<TF>(f->vt), mp<TF>(f->wt), gd.dzhi, \
+                           gd.dxi_t, gd.dyi_t, g->itot, g->jtot, g->jmax, g->kmax, g->igc, g->jgc, g->kgc, g->icells, g->jcells); \
+        else hipLaunchKernelGGL((unpack_out_slab_kernel<false, TF>), ug, dim3(256), 0, st, mp<TF>(f->p), cp<TF>(P->packed), mp<TF>(f->ut), mp<TF>(f->vt), mp<TF>(f->wt), gd.dzhi, \
+                           gd.dxi_t, gd.dyi_t, g->itot, g->jtot, g->jmax, g->kmax, g->igc, g->jgc, g->kgc, g->icells, g->jcells); return (int)MHH_OK; }()
     if (int e = MHH_DISPATCH(g, CALL)) return e;
 #undef CALL
     MHH_LAUNCH_CHECK();

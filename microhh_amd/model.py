@@ -56,7 +56,7 @@ class HotPath:
     """Device-resident fields of ONE rank + the operator calls of one sub-step."""
 
     def __init__(self, case, itot, jtot, ktot, dtype=np.float64, device="cuda:0", seed=666, dt=1.0,
-                 lib=None, npy=1, rank=0, group=None, global_init=None, force_slab=False, slim_halos=True, overlap=None):
+                 lib=None, npy=1, rank=0, group=None, global_init=None, force_slab=False, slim_halos=True, overlap=None, pres_chunks=None):
         import torch
         self.torch = torch
         self.lib = lib if lib is not None else capi.lib()
@@ -174,6 +174,15 @@ class HotPath:
             self.xsend = torch.zeros(2*nx, device=self.device, dtype=td)
             self.xrecv = torch.zeros(2*nx, device=self.device, dtype=td)
             self._halo = {}
+            # k-slices of the pressure solve: the all-to-all of slice c travels (second stream) while slice c+1 is transformed.
+            # Default with more than one rank: 4 slices where ktot allows (MHH_PRES_CHUNKS / pres_chunks override; 1 = unsliced).
+            if pres_chunks is None:
+                env = os.environ.get("MHH_PRES_CHUNKS")
+                pres_chunks = int(env) if env else (4 if npy > 1 else 1)
+            while pres_chunks > 1 and (ktot % pres_chunks or not self.slim):
+                pres_chunks -= 1
+            self.pres_chunks = pres_chunks
+            self._ok(self.lib.mhh_pres_slab_set_chunks(self.plan, pres_chunks))
         self._prog = [self.u, self.v, self.w] + self.s
         self.evisc_local_ghosts = self.slab and self.slim and cfg["diff"] == DIFF_SMAG2 and g.jgc >= 2
         if self.evisc_local_ghosts:
@@ -390,6 +399,9 @@ class HotPath:
         else:         self.halo([self.vt])
         packed = lib.mhh_pres_slab_packed(self.plan)
         self._ok(lib.mhh_pres_input_packed(self.G, 2, C.byref(self.fields), self.dt, packed, st))
+        if self.pres_chunks > 1:
+            self._pres_sliced(packed)
+            return
         self._ok(lib.mhh_pres_fwd_x_pack(self.plan, self.G, packed, self.xsend.data_ptr(), st))
         self._transpose()                                                    # Transpose::exec_xy
         self._ok(lib.mhh_pres_fwd_y_solve_bwd_y(self.plan, self.G, self.xrecv.data_ptr(), self.xsend.data_ptr(), self.stream))
@@ -405,19 +417,71 @@ class HotPath:
             self.halo([self.p])
             self._ok(lib.mhh_pres_output_order(self.G, 2, C.byref(self.fields), self.stream))
 
-    def _transpose(self):
+    def _pres_sliced(self, packed):
+        """Pres_2::exec after the input stage, in k-slices: per slice x transform + pack, all-to-all on the exchange stream while
+        the next slice is transformed, y transform as each slice arrives; Thomas sweeps over all levels; the same on the way back.
+        Same kernels per plane as the unsliced path (tests/test_slab_gloo.py compares the two)."""
+        lib, torch, n = self.lib, self.torch, self.pres_chunks
+        seg = self.xsend.numel() // n
+        F = C.byref(self.fields)
+        two_streams = self.on_gpu and not self._host_staged and (self.npy > 1 or self._force_comm)
+        if two_streams:
+            main = torch.cuda.current_stream(self.device)
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream(self.device)
+                self._ev = [torch.cuda.Event(), torch.cuda.Event()]
+            if not hasattr(self, "_sl_ev"):
+                self._sl_ev = [[torch.cuda.Event() for _ in range(n)] for _ in range(4)]
+
+        def exchange(c, ready, done):
+            """all-to-all of slice c: on the exchange stream once `ready` (recorded on the main stream) has passed"""
+            a, b = self.xsend[c*seg:(c+1)*seg], self.xrecv[c*seg:(c+1)*seg]
+            if not two_streams:
+                self._transpose(a, b)
+                return
+            ready.record(main)
+            self._comm_stream.wait_event(ready)
+            with torch.cuda.stream(self._comm_stream):
+                self._transpose(a, b)
+                done.record(self._comm_stream)
+
+        for c in range(n):
+            self._ok(lib.mhh_pres_fwd_x_pack_chunk(self.plan, self.G, packed, self.xsend.data_ptr(), c, self.stream))
+            exchange(c, *( (self._sl_ev[0][c], self._sl_ev[1][c]) if two_streams else (None, None) ))
+        for c in range(n):
+            if two_streams:
+                main.wait_event(self._sl_ev[1][c])
+            self._ok(lib.mhh_pres_fwd_y_chunk(self.plan, self.G, self.xrecv.data_ptr(), c, self.stream))
+        self._ok(lib.mhh_pres_solve_y(self.plan, self.G, self.stream))
+        for c in range(n):
+            self._ok(lib.mhh_pres_bwd_y_chunk(self.plan, self.G, self.xsend.data_ptr(), c, self.stream))
+            exchange(c, *( (self._sl_ev[2][c], self._sl_ev[3][c]) if two_streams else (None, None) ))
+        for c in range(n):
+            if two_streams:
+                main.wait_event(self._sl_ev[3][c])
+            self._ok(lib.mhh_pres_bwd_x_chunk(self.plan, self.G, self.xrecv.data_ptr(), c, self.stream))
+        self._ok(lib.mhh_pres_unpack_output_slab(self.plan, self.G, F, self.stream))
+        self.halo([self.p], rows_south=0, rows_north=1)
+        self._ok(lib.mhh_pres_output_south_row(self.G, F, self.stream))
+
+    def _transpose(self, send=None, recv=None):
         """x<->y transpose of the spectral pressure: one equal-split all-to-all (RCCL over xGMI)."""
+        if send is not None:
+            return self._transpose_buffers(send, recv)
+        return self._transpose_buffers(self.xsend, self.xrecv)
+
+    def _transpose_buffers(self, xsend, xrecv):
         if self.npy == 1 and not self._force_comm:
-            self.xrecv.copy_(self.xsend)
+            xrecv.copy_(xsend)
             return
         import torch.distributed as dist
         if self._host_staged:
-            hs = self.xsend.cpu(); hr = self.torch.empty_like(hs)
+            hs = xsend.cpu(); hr = self.torch.empty_like(hs)
             dist.all_to_all_single(hr, hs, group=self.group)
-            self.xrecv.copy_(hr)
+            xrecv.copy_(hr)
             return
         with self._timed("transpose"):
-            dist.all_to_all_single(self.xrecv, self.xsend, group=self.group)
+            dist.all_to_all_single(xrecv, xsend, group=self.group)
 
     def step(self):
         """One full RHS + pressure evaluation (the BASELINE metric's unit of work)."""

@@ -115,3 +115,20 @@ def test_slab_ranks_save_restart_files_concurrently():
         for n in names + ["grid"]:
             fn = "%s.%07d" % (n, 0 if n == "grid" else 3)
             assert open(os.path.join(one, fn), "rb").read() == open(os.path.join(two, fn), "rb").read(), fn
+
+
+def test_sliced_pressure_solve_equals_unsliced_on_one_rank():
+    """The k-sliced form of the slab pressure solve (mhh_pres_*_chunk: slice c of the all-to-all can travel while slice c+1 is
+    transformed) against the unsliced calls, one rank, emulated kernels: every plane takes the same transforms -> same bits."""
+    lib = B.get("emul").lib
+    gi = synthetic_global("drycblles", *GRID)
+    out = {}
+    for n in (1, 2, 5):
+        hp = HotPath("drycblles", *GRID, device="cpu", lib=lib, global_init=gi, force_slab=True, pres_chunks=n)
+        assert hp.pres_chunks == n
+        hp.cyclic_prognostic(); hp.exec_viscosity(); hp.rhs(); hp.pres()
+        out[n] = {k: _interior(hp, getattr(hp, k)) for k in ("p", "ut", "vt", "wt")}
+        hp.close()
+    for n in (2, 5):
+        for k in ("p", "ut", "vt", "wt"):
+            assert np.array_equal(out[n][k], out[1][k]), (n, k)

@@ -84,7 +84,7 @@ def test_slab_ranks_on_one_gpu_match_single_rank(world, overlap):
             assert abs(float(p["div"]) - float(ref["div"])) <= 1e-12 * abs(float(ref["div"])) + 1e-18
 
 
-def _rccl_worker(rank, port, tmp, overlap):
+def _rccl_worker(rank, port, tmp, overlap, chunks):
     import torch
     import torch.distributed as dist
     from microhh_amd.model import HotPath, synthetic_global
@@ -93,7 +93,8 @@ def _rccl_worker(rank, port, tmp, overlap):
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
-        hp = HotPath("drycblles", *GRID, device="cuda:0", npy=1, rank=0, force_slab=True, global_init=synthetic_global("drycblles", *GRID), overlap=overlap)
+        hp = HotPath("drycblles", *GRID, device="cuda:0", npy=1, rank=0, force_slab=True, global_init=synthetic_global("drycblles", *GRID), overlap=overlap, pres_chunks=chunks)
+        assert hp.pres_chunks == chunks
         assert hp._force_comm and not hp._host_staged and hp.evisc_local_ghosts
         out = {}
         _run(hp, out, overlapped=overlap)
@@ -103,10 +104,11 @@ def _rccl_worker(rank, port, tmp, overlap):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap", [False, True], ids=["plain", "overlap"])
-def test_slab_code_path_through_real_rccl_on_one_rank(overlap):
+@pytest.mark.parametrize("overlap,chunks", [(False, 1), (True, 1), (True, 4)], ids=["plain", "overlap", "overlap-sliced-transposes"])
+def test_slab_code_path_through_real_rccl_on_one_rank(overlap, chunks):
     """The slab code path with its exchanges going through RCCL itself (nccl backend, one-rank communicator, MHH_FORCE_COMM=1:
-    halos as batch_isend_irecv to self, the transposes as all_to_all_single, maxima as all_reduce) -- device buffers handed
+    halos as batch_isend_irecv to self, the transposes as all_to_all_single -- whole or in four k-slices on the exchange
+    stream while the next slice is transformed --, maxima as all_reduce) -- device buffers handed
     to the collectives as in production, stream ordering between the kernels and RCCL included. Same bits as the plain run."""
     import torch.multiprocessing as mp
     from microhh_amd.model import HotPath, synthetic_global
@@ -115,7 +117,7 @@ def test_slab_code_path_through_real_rccl_on_one_rank(overlap):
     _run(hp, ref)
     hp.close()
     with tempfile.TemporaryDirectory() as tmp:
-        mp.spawn(_rccl_worker, args=(29900 + int(overlap) + os.getpid() % 1000, tmp, overlap), nprocs=1, join=True)
+        mp.spawn(_rccl_worker, args=(29900 + int(overlap) + 2*chunks + os.getpid() % 1000, tmp, overlap, chunks), nprocs=1, join=True)
         got = np.load(os.path.join(tmp, "rank0.npz"))
         for key in ("evisc", "rhs_ut", "rhs_vt", "rhs_wt", "rhs_st"):
             assert np.array_equal(got[key], ref[key]), key
