@@ -161,6 +161,7 @@ def main():
     ap.add_argument("--build", default="default", choices=["default", "fma"],
                     help="fma = the second, named build (microhh_amd/libmhh_hip_fma.so: marching kernels with FMA contraction; "
                          "tolerance stated in tests/test_fma_build.py) instead of the bit-exact default")
+    ap.add_argument("--no-fma-line", action="store_true", help="skip the extra timing of the named FMA build (fma_build in the JSON line)")
     ap.add_argument("--force-slab", action="store_true", help="N=1 only: run the slab code path (halo pack/unpack, split pressure solve) with local copies as exchanges")
     args = ap.parse_args()
 
@@ -291,7 +292,7 @@ def main():
         out["roofline"]["traffic"], src = recorded_traffic(args.workload)      # FETCH_SIZE x 2 + WRITE_SIZE per launch, or null
         if src:
             out["roofline"]["traffic_source"] = src
-    if world == 1 and on_gpu and args.build == "default" and not args.unfused and not rhs_only and not os.environ.get("MHH_LIB") \
+    if world == 1 and on_gpu and args.build == "default" and not args.unfused and not rhs_only and not args.no_fma_line and not os.environ.get("MHH_LIB") \
             and os.path.exists(os.path.join(ROOT, "microhh_amd", "libmhh_hip_fma.so")):
         # the same fused RHS launch from the named FMA build, timed the same way (its own fields; nothing of it enters `value`)
         from microhh_amd import capi

@@ -34,6 +34,10 @@
 
 using namespace mhh;
 
+#ifdef MHH_FMA_BUILD     // the named FMA build (build.py): its kernels carry their own name in profiler output
+#define rhs25_march_kernel rhs25_march_fma_kernel
+#endif
+
 namespace
 {
 // 6-level register window of a column: logical index n holds level k-2+n; with rotation R it lives in w[(n+R) % 6]

@@ -20,6 +20,10 @@
 
 using namespace mhh;
 
+#ifdef MHH_FMA_BUILD     // the named FMA build (build.py): its kernels carry their own name in profiler output
+#define rhs44_march_kernel rhs44_march_fma_kernel
+#endif
+
 namespace
 {
 template<class TF> struct March4Fields

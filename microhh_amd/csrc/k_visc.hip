@@ -16,6 +16,10 @@
 
 using namespace mhh;
 
+#ifdef MHH_FMA_BUILD     // the named FMA build (build.py): its kernels carry their own name in profiler output
+#define visc_march_kernel visc_march_fma_kernel
+#endif
+
 namespace
 {
 template<class TF> struct ViscFields

@@ -9,7 +9,7 @@ mkdir -p $OUT
 for v in "" $(ls microhh_amd/variants/*.so 2>/dev/null); do
   name=$(basename "${v:-default}" .so)
   export MHH_LIB=${v:+$PWD/$v}
-  timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQC_ICACHE_REQ SQC_ICACHE_MISSES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_IFETCH --kernel-trace --output-format csv -d $OUT/$name -- python3 bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline > $OUT/$name.json 2> $OUT/$name.err || { echo "$name failed"; tail -2 $OUT/$name.err; }
+  timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQC_ICACHE_REQ SQC_ICACHE_MISSES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_IFETCH --kernel-trace --output-format csv -d $OUT/$name -- python3 bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline --no-fma-line > $OUT/$name.json 2> $OUT/$name.err || { echo "$name failed"; tail -2 $OUT/$name.err; }
   python3 - $OUT/$name "$PAT" "$name" <<'PY'
 import csv, glob, sys, collections
 vals = collections.defaultdict(list); dur = []

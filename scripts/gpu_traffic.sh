@@ -10,7 +10,7 @@ for v in "" $(ls microhh_amd/variants/*.so 2>/dev/null); do
   name=$(basename "${v:-default}" .so)
   export MHH_LIB=${v:+$PWD/$v}
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$name/$c -- python3 bench.py --workload $WL --steps 2 --warmup 1 --no-cpu-baseline > $OUT/$name.$c.json 2> $OUT/$name.$c.err || { echo "$name $c failed"; tail -2 $OUT/$name.$c.err; }
+    timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$name/$c -- python3 bench.py --workload $WL --steps 2 --warmup 1 --no-cpu-baseline --no-fma-line > $OUT/$name.$c.json 2> $OUT/$name.$c.err || { echo "$name $c failed"; tail -2 $OUT/$name.$c.err; }
   done
   python3 - $OUT/$name "$PAT" "$name" "$WL" <<'PY'
 import csv, glob, sys
