@@ -265,6 +265,13 @@ int  mhh_pres_plan_create(const mhh_grid* g, int order /*2|4*/,
 void mhh_pres_plan_destroy(mhh_pres_plan* plan);
 /* Pres::exec(dt): input -> solve -> output (src/pres_2.cxx:66-94, pres_4.cxx:64-140) */
 int mhh_pres_exec(mhh_pres_plan* plan, const mhh_grid* g, const mhh_fields* f, double dt, void* stream);
+/* pres_2 with power-of-two itot, jtot: mhh_pres_exec runs three kernels that do the transforms in LDS (csrc/pres_lds.h)
+ * instead of the seven passes of the staged form (MHH_PRES_LDS=0 selects the staged form). The stages one by one, for tests:
+ * 1 = Pres_2::input + transform along x (src/pres_2.cxx:156-196, src/fft.cxx:451-497), 2 = transforms along y around the
+ * Thomas sweeps (src/pres_2.cxx:202-263), 3 = transform back along x + p with ghost cells + Pres_2::output (:333-387).      */
+int   mhh_pres_lds_stage(mhh_pres_plan* plan, const mhh_grid* g, const mhh_fields* f, double dt, int stage, void* stream);
+int   mhh_pres_plan_has_lds_form(const mhh_pres_plan* plan);
+void* mhh_pres_plan_spectral(mhh_pres_plan* plan);   /* device array between the stages: S[k][kx][j], complex */
 /* stages, exposed for the slab-decomposed driver and for parity tests */
 int mhh_pres_input (mhh_pres_plan* plan, const mhh_grid* g, const mhh_fields* f, double dt, void* p_packed, void* stream); /* pres_2.cxx:156-196, pres_4.cxx:256-317 */
 int mhh_pres_solve (mhh_pres_plan* plan, const mhh_grid* g, const mhh_fields* f, void* p_packed, void* stream);            /* pres_2.cxx:267-362, pres_4.cxx:320-529 */

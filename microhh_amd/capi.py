@@ -78,6 +78,9 @@ SIGNATURES = {
     "mhh_pres_plan_create": (ci, [GP, ci, vp, vp, vp, vp, vp, vp, C.POINTER(PLAN)]),
     "mhh_pres_plan_destroy": (None, [PLAN]),
     "mhh_pres_exec": (ci, [PLAN, GP, FP, cd, vp]),
+    "mhh_pres_lds_stage": (ci, [PLAN, GP, FP, cd, ci, vp]),
+    "mhh_pres_plan_has_lds_form": (ci, [PLAN]),
+    "mhh_pres_plan_spectral": (vp, [PLAN]),
     "mhh_pres_input": (ci, [PLAN, GP, FP, cd, vp, vp]),
     "mhh_pres_solve": (ci, [PLAN, GP, FP, vp, vp]),
     "mhh_pres_output": (ci, [PLAN, GP, FP, vp]),

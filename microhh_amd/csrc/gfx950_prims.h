@@ -154,6 +154,9 @@ template<class T> __device__ __forceinline__ void gstore_stream(T* uniform_base,
 }
 // Opaque re-definition of a per-lane value (no instruction): what is computed from it cannot be hoisted above this point.
 __device__ __forceinline__ void keep_vgpr(unsigned& x) { asm volatile("" : "+v"(x)); }
+// v_rcp_f64 / v_rcp_f32: the hardware's reciprocal seed (refined by the caller)
+__device__ __forceinline__ double recip_seed(double x) { return __builtin_amdgcn_rcp(x); }
+__device__ __forceinline__ float  recip_seed(float x)  { return __builtin_amdgcn_rcpf(x); }
 // No instruction is scheduled across this point (bounds the live ranges the instruction scheduler creates by hoisting loads).
 #ifndef MHH_NO_SCHED_FENCE
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }

@@ -45,10 +45,14 @@ struct mhh_pres_plan
     void* cb_data = nullptr; bool cb_ready = false;
     void* fwd_wb = nullptr; void* bwd_wb = nullptr;
     bool fft_setup = false;
+    // the three-kernel form with the transforms in LDS (pres_lds.h): twiddle tables, w3 in its [k][kx][ky] layout
+    void* tx = nullptr; void* ty = nullptr; void* w3l = nullptr;
+    bool lds_ok = false;
 };
 
 
 template<class TF> struct C2 { TF x, y; };
+#include "pres_lds.h"
 
 // ---- host-side coefficient tables (Pres_2::set_values src/pres_2.cxx:125-153; Pres_4::set_values src/pres_4.cxx:179-252)
 template<class TF>
@@ -183,7 +187,7 @@ MHH_API void mhh_pres_plan_destroy(mhh_pres_plan* P)
     if (P->bwd_info) rocfft_execution_info_destroy(P->bwd_info);
     if (P->fwd_info_cb) rocfft_execution_info_destroy(P->fwd_info_cb);
     if (P->bwd_info_cb) rocfft_execution_info_destroy(P->bwd_info_cb);
-    void* bufs[] = {P->cb_data, P->bmati, P->bmatj, P->a, P->c, P->dz, P->rhoref, P->packed, P->spec, P->work, P->fwd_wb, P->bwd_wb,
+    void* bufs[] = {P->tx, P->ty, P->w3l, P->cb_data, P->bmati, P->bmatj, P->a, P->c, P->dz, P->rhoref, P->packed, P->spec, P->work, P->fwd_wb, P->bwd_wb,
                     P->m[0], P->m[1], P->m[2], P->m[3], P->m[4], P->m[5], P->m[6]};
     for (void* b : bufs) if (b) (void)hipFree(b);
     delete P;
@@ -192,6 +196,7 @@ MHH_API void mhh_pres_plan_destroy(mhh_pres_plan* P)
 static int hdma_factor(mhh_pres_plan* P);
 static int tdma_factor(mhh_pres_plan* P);
 static int pres_cb_setup(mhh_pres_plan* P);
+static int pres_lds_setup(mhh_pres_plan* P, const mhh_grid* g);
 MHH_API int mhh_pres_plan_create(const mhh_grid* g, int order, const void* host_dz, const void* host_dzhi, const void* host_dzi4, const void* host_dzhi4,
                                  const void* host_rhoref, const void* host_rhorefh, mhh_pres_plan** out)
 {
@@ -228,6 +233,7 @@ MHH_API int mhh_pres_plan_create(const mhh_grid* g, int order, const void* host_
     }
     if (!e && order == 4) e = hdma_factor(P);
     if (!e && order == 2) e = tdma_factor(P);
+    if (!e && order == 2) e = pres_lds_setup(P, g);
     if (e) { mhh_pres_plan_destroy(P); return e; }
     *out = P;
     return MHH_OK;
@@ -865,12 +871,121 @@ static int pres_exec_fused(mhh_pres_plan* P, const mhh_grid* g, const mhh_fields
     return MHH_OK;
 }
 
+// =======================================================================================================
+// Pres_2::exec with the transforms in LDS (pres_lds.h): input + x transform | y transforms around the Thomas sweeps |
+// x transform + p + output. Power-of-two itot (16 .. 1024) and jtot (8 .. 1024) whose rows fit the LDS; everything else
+// takes the staged form above.
+// =======================================================================================================
+#ifndef MHH_PRES_LDS_RG
+#define MHH_PRES_LDS_RG 2          // rows whose loads a thread of the x-stage kernels keeps in flight together
+#endif
+static constexpr int LDS_RG = MHH_PRES_LDS_RG;
+static int ilog2(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
+static size_t lds_bytes_x(const mhh_pres_plan* P, int rows) { return ((size_t)rows*(lds_fft::lpad(P->itot/2) + 2) + P->itot) * 2*P->esz; }
+static size_t lds_bytes_y(const mhh_pres_plan* P)           { return ((size_t)8*lds_fft::lpad(P->jtot) + P->jtot) * 2*P->esz; }
+template<class TF>
+static lds_fft::PresLdsSolve<TF> lds_solve_args(const mhh_pres_plan* P)
+{
+    return lds_fft::PresLdsSolve<TF>{static_cast<C2<TF>*>(P->spec), cp<TF>(P->w3l), cp<TF>(P->bmati), cp<TF>(P->bmatj), cp<TF>(P->a), cp<TF>(P->c),
+                                     cp<TF>(P->dz), cp<TF>(P->rhoref), static_cast<const C2<TF>*>(P->ty), P->itot/2, P->jtot, ilog2(P->jtot), P->ktot};
+}
+template<class TF>
+static int pres_lds_setup_t(mhh_pres_plan* P)
+{
+    const double pi = std::acos(-1.);
+    for (int d=0; d<2; ++d)
+    {
+        const int n = d ? P->jtot : P->itot;
+        std::vector<TF> t(2*(size_t)n);
+        for (int m=0; m<n; ++m) { t[2*m] = (TF)std::cos(2.*pi*m/n); t[2*m+1] = (TF)(-std::sin(2.*pi*m/n)); }
+        // the quarter points exactly
+        t[0] = 1; t[1] = 0; t[n] = -1; t[n+1] = 0;
+        if (n >= 4) { t[n/2] = 0; t[n/2+1] = -1; t[3*n/2] = 0; t[3*n/2+1] = 1; }
+        if (int e = upload(d ? &P->ty : &P->tx, t)) return e;
+    }
+    MHH_HIP_TRY(hipMalloc(&P->w3l, (size_t)(P->itot/2 + 1)*P->jtot*P->ktot*sizeof(TF)));
+    hipLaunchKernelGGL(lds_fft::pres_lds_factor_kernel<TF>, dim3((P->jtot + 63)/64, P->itot/2 + 1), dim3(64), 0, 0, static_cast<TF*>(P->w3l), lds_solve_args<TF>(P));
+    MHH_LAUNCH_CHECK();
+    MHH_HIP_TRY(hipStreamSynchronize(0));
+    MHH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_fft::pres_in_fftx_kernel<TF, LDS_RG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_x(P, 8)));
+    MHH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_fft::pres_ysolve_kernel<TF, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_y(P)));
+    MHH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_fft::pres_ysolve_kernel<TF, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_y(P)));
+    MHH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_fft::pres_ifftx_out_kernel<TF, LDS_RG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_x(P, 9)));
+    return MHH_OK;
+}
+static int pres_lds_setup(mhh_pres_plan* P, const mhh_grid* g)
+{
+    const size_t lds_max = 160*1024;
+    if (!(is_pow2(P->itot) && P->itot >= 16 && P->itot <= 1024 && is_pow2(P->jtot) && P->jtot >= 8 && P->jtot <= 1024)) return MHH_OK;
+    if (lds_bytes_x(P, 9) > lds_max || lds_bytes_y(P) > lds_max) return MHH_OK;
+    if (g->igc > P->itot || g->jgc > P->jtot) return MHH_OK;
+    if (int e = (P->dtype == MHH_F64) ? pres_lds_setup_t<double>(P) : pres_lds_setup_t<float>(P)) return e;
+    P->lds_ok = true;
+    return MHH_OK;
+}
+static int lds_levels_per_block(const mhh_pres_plan* P)
+{
+    const char* e = getenv("MHH_PRES_LDS_KC");
+    const int kc = e ? atoi(e) : 32;
+    return kc < 1 ? 1 : (kc > P->ktot ? P->ktot : kc);
+}
+// the three stages, also callable one by one (tests): 1 = input + x transform, 2 = y transforms + Thomas, 3 = x transform + p + output
+MHH_API int mhh_pres_lds_stage(mhh_pres_plan* P, const mhh_grid* g, const mhh_fields* f, double dt, int stage, void* stream)
+{
+    if (int e = check_grid(g)) return e;
+    MHH_REQUIRE(P && P->lds_ok, "plan has no LDS-transform form (pres_2, power-of-two itot and jtot)");
+    MHH_REQUIRE(P->dtype == g->dtype && P->itot == g->itot && P->jtot == g->jtot && P->ktot == g->ktot && g->npy == 1, "plan/grid mismatch");
+    MHH_REQUIRE(stage >= 1 && stage <= 3, "stage");
+    hipStream_t st = as_stream(stream);
+    const int kc = lds_levels_per_block(P);
+    const dim3 xgrid(P->jtot/8, (P->ktot + kc-1)/kc);
+    if (stage == 1)
+    {
+        MHH_REQUIRE(f && f->u && f->v && f->w && f->ut && f->vt && f->wt && f->rhoref && f->rhorefh, "null field");
+        MHH_REQUIRE(dt > 0., "dt");
+        if (int e = pres_input_halos(g, 2, f, stream)) return e;
+#define CALL(TF) [&]{ lds_fft::PresLdsIn<TF> a{make_grid<TF>(g), cp<TF>(f->u), cp<TF>(f->v), cp<TF>(f->w), cp<TF>(f->ut), cp<TF>(f->vt), cp<TF>(f->wt), \
+                          cp<TF>(f->rhoref), cp<TF>(f->rhorefh), TF(1.)/TF(dt), static_cast<C2<TF>*>(P->spec), static_cast<const C2<TF>*>(P->tx), ilog2(P->itot/2), kc}; \
+                      hipLaunchKernelGGL((lds_fft::pres_in_fftx_kernel<TF, LDS_RG>), xgrid, dim3(P->itot), lds_bytes_x(P, 8), st, a); return MHH_OK; }()
+        if (int e = MHH_DISPATCH(g, CALL)) return e;
+#undef CALL
+    }
+    else if (stage == 2)
+    {
+#define CALL(TF) [&]{ if (P->jtot <= 512) hipLaunchKernelGGL((lds_fft::pres_ysolve_kernel<TF, 512>), dim3(P->itot/2), dim3(P->jtot), lds_bytes_y(P), st, lds_solve_args<TF>(P)); \
+                      else                hipLaunchKernelGGL((lds_fft::pres_ysolve_kernel<TF, 1024>), dim3(P->itot/2), dim3(P->jtot), lds_bytes_y(P), st, lds_solve_args<TF>(P)); return MHH_OK; }()
+        if (int e = MHH_DISPATCH(g, CALL)) return e;
+#undef CALL
+    }
+    else
+    {
+        MHH_REQUIRE(f && f->p && f->ut && f->vt && f->wt, "null field");
+#define CALL(TF) [&]{ lds_fft::PresLdsOut<TF> a{make_grid<TF>(g), static_cast<const C2<TF>*>(P->spec), static_cast<const C2<TF>*>(P->tx), \
+                          mp<TF>(f->p), mp<TF>(f->ut), mp<TF>(f->vt), mp<TF>(f->wt), ilog2(P->itot/2), kc}; \
+                      hipLaunchKernelGGL((lds_fft::pres_ifftx_out_kernel<TF, LDS_RG>), xgrid, dim3(P->itot), lds_bytes_x(P, 9), st, a); return MHH_OK; }()
+        if (int e = MHH_DISPATCH(g, CALL)) return e;
+#undef CALL
+    }
+    MHH_LAUNCH_CHECK();
+    return MHH_OK;
+}
+// 1 if the plan can run (and mhh_pres_exec will by default run) the LDS-transform form
+MHH_API int mhh_pres_plan_has_lds_form(const mhh_pres_plan* P) { return (P && P->lds_ok) ? 1 : 0; }
+// the spectral array between the stages (tests): S[k][kx][j], complex
+MHH_API void* mhh_pres_plan_spectral(mhh_pres_plan* P) { return P ? P->spec : nullptr; }
+
 MHH_API int mhh_pres_exec(mhh_pres_plan* P, const mhh_grid* g, const mhh_fields* f, double dt, void* stream)
 {
     MHH_REQUIRE(P != nullptr, "plan");
     // Opt-in (MHH_PRES_FUSED=1). Measured on MI355X: identical bits, but the transforms run the heavy producer through an
     // indirect call per element and lose more than the two saved array passes give back (512^3: 15.7 ms vs 14.7 ms per step;
     // 512x256x256 pres_4: 4.05 vs 3.42 ms), so the staged form stays the default.
+    const char* le = getenv("MHH_PRES_LDS");                                  // "0": the staged form also where the LDS form exists
+    if (P->lds_ok && !(le && !strcmp(le, "0")))
+    {
+        for (int stage=1; stage<=3; ++stage) if (int e = mhh_pres_lds_stage(P, g, f, dt, stage, stream)) return e;
+        return MHH_OK;
+    }
     const char* env = getenv("MHH_PRES_FUSED");
     if (!P->cb_ready || !(env && !strcmp(env, "1")))
     {

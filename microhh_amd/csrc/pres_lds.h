@@ -1,0 +1,525 @@
+// pres_lds.h -- Pres_2::exec (src/pres_2.cxx:66-94) as THREE kernels with the transforms done in LDS, for power-of-two itot, jtot.
+//
+// The staged form (k_pres.hip) is seven passes over memory: input | x r2c | y c2c | Thomas | y c2c | x c2r | unpack + output,
+// each a read and a write of a 512^3 array or more. The transforms are short (a row fits a fraction of a CU's 160 KB LDS), so
+// they can ride inside the kernels on either side of them:
+//
+//   pres_in_fftx_kernel   Pres_2::input (src/pres_2.cxx:156-196) -> LDS -> real-to-complex transform of 8 rows along x
+//                         (fft_forward's first half, src/fft.cxx:451-497) -> spectral array S[k][kx][j]
+//   pres_ysolve_kernel    per kx: forward transform along y of 8 levels in LDS, the Thomas forward sweep over them
+//                         (src/pres_2.cxx:213-249), down through all levels; then back up: back substitution (:251-263),
+//                         inverse transform along y, S[k][kx][j] again (now physical in y)
+//   pres_ifftx_out_kernel complex-to-real transform of 9 rows along x in LDS (fft_backward's second half, src/fft.cxx:540-583),
+//                         normalisation, p with its ghost cells (src/pres_2.cxx:333-363) and Pres_2::output (:365-387)
+//
+// 19.5 array passes instead of 27.5. The transforms are Stockham radix-8 / 4 / 2 passes on 16-byte (fp64) or 8-byte (fp32)
+// complex numbers, eight elements per thread and pass, twiddles from a table made on the host in double precision. The
+// reference's transforms are FFTW's; like rocFFT's these agree with them to rounding (DESIGN.md "Parity": the pressure is the
+// toleranced part of the path).
+#pragma once
+#include <gfx950_prims.h>   // angle form: the CPU emulation build (tests/emul) overrides it by include path
+
+namespace mhh { namespace lds_fft {
+
+template<class TF> __device__ __forceinline__ C2<TF> operator+(C2<TF> a, C2<TF> b) { return C2<TF>{a.x + b.x, a.y + b.y}; }
+template<class TF> __device__ __forceinline__ C2<TF> operator-(C2<TF> a, C2<TF> b) { return C2<TF>{a.x - b.x, a.y - b.y}; }
+
+// one complex number in eight falls on a new 128-byte bank row: strided passes stay conflict-free
+__host__ __device__ __forceinline__ int lpad(int i) { return i + (i >> 3); }
+
+// S < 0: forward (e^{-i..}), S > 0: inverse. t = table entry exp(-i phi).
+template<int S, class TF> __device__ __forceinline__ C2<TF> mul_tw(C2<TF> a, C2<TF> t)
+{
+    return S < 0 ? C2<TF>{a.x*t.x - a.y*t.y, a.x*t.y + a.y*t.x} : C2<TF>{a.x*t.x + a.y*t.y, a.y*t.x - a.x*t.y};
+}
+template<int S, class TF> __device__ __forceinline__ C2<TF> rot(C2<TF> a) { return S < 0 ? C2<TF>{a.y, -a.x} : C2<TF>{-a.y, a.x}; }   // a * (S i)
+template<int S, class TF> __device__ __forceinline__ void dft4(C2<TF>& a0, C2<TF>& a1, C2<TF>& a2, C2<TF>& a3)
+{
+    const C2<TF> s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = rot<S>(a1 - a3);
+    a0 = s02 + s13; a1 = d02 + d13; a2 = s02 - s13; a3 = d02 - d13;
+}
+template<int S, class TF> __device__ __forceinline__ void dft8(C2<TF> (&v)[8])
+{
+    const TF h = TF(0.70710678118654752440);
+    C2<TF> t0 = v[0] + v[4], u0 = v[0] - v[4], t1 = v[1] + v[5], u1 = v[1] - v[5];
+    C2<TF> t2 = v[2] + v[6], u2 = v[2] - v[6], t3 = v[3] + v[7], u3 = v[3] - v[7];
+    // u_k *= exp(S i pi k / 4)
+    u1 = S < 0 ? C2<TF>{(u1.x + u1.y)*h, (u1.y - u1.x)*h} : C2<TF>{(u1.x - u1.y)*h, (u1.x + u1.y)*h};
+    u2 = rot<S>(u2);
+    u3 = S < 0 ? C2<TF>{(u3.y - u3.x)*h, -(u3.x + u3.y)*h} : C2<TF>{-(u3.x + u3.y)*h, (u3.x - u3.y)*h};
+    dft4<S>(t0, t1, t2, t3); dft4<S>(u0, u1, u2, u3);
+    v[0] = t0; v[2] = t1; v[4] = t2; v[6] = t3; v[1] = u0; v[3] = u1; v[5] = u2; v[7] = u3;
+}
+
+// One Stockham pass over a transform of N = 2^n points that lives in LDS at D[lpad(0..N-1)], done by N/8 threads (l = 0..N/8-1),
+// every thread owning eight elements. gather: all reads of the pass; scatter: twiddles, butterflies of radix 2^lr (8 / lr of them
+// per thread), writes. The caller puts a barrier between the two and after. ls = log2 of the product of the radices already done.
+// T[m << tshift] = exp(-2 pi i m / N).
+template<class TF> __device__ __forceinline__ void fft_gather(const C2<TF>* D, int l, int n, C2<TF> (&v)[8])
+{
+    const int n8 = 1 << (n-3);
+#pragma unroll
+    for (int m=0; m<8; ++m) v[m] = D[lpad(l + m*n8)];
+}
+template<int S, class TF> __device__ __forceinline__ void fft_scatter(C2<TF>* D, const C2<TF>* T, int tshift, int l, int n, int lr, int ls, C2<TF> (&v)[8])
+{
+    const int n8 = 1 << (n-3), mask = (1 << ls) - 1, q = n - ls - lr + tshift;
+    if (lr == 3)
+    {
+        const int k = l & mask;
+        if (ls > 0)
+        {
+#pragma unroll
+            for (int r=1; r<8; ++r) v[r] = mul_tw<S>(v[r], T[(r*k) << q]);
+        }
+        dft8<S>(v);
+        const int o = ((l - k) << 3) + k;
+#pragma unroll
+        for (int r=0; r<8; ++r) D[lpad(o + (r << ls))] = v[r];
+    }
+    else if (lr == 2)
+    {
+#pragma unroll
+        for (int b=0; b<2; ++b)
+        {
+            const int j = l + b*n8, k = j & mask;
+            C2<TF> a0 = v[b], a1 = v[b+2], a2 = v[b+4], a3 = v[b+6];
+            if (ls > 0) { a1 = mul_tw<S>(a1, T[k << q]); a2 = mul_tw<S>(a2, T[(2*k) << q]); a3 = mul_tw<S>(a3, T[(3*k) << q]); }
+            dft4<S>(a0, a1, a2, a3);
+            const int o = ((j - k) << 2) + k;
+            D[lpad(o)] = a0; D[lpad(o + (1 << ls))] = a1; D[lpad(o + (2 << ls))] = a2; D[lpad(o + (3 << ls))] = a3;
+        }
+    }
+    else
+    {
+#pragma unroll
+        for (int b=0; b<4; ++b)
+        {
+            const int j = l + b*n8, k = j & mask;
+            C2<TF> a0 = v[b], a1 = v[b+4];
+            if (ls > 0) a1 = mul_tw<S>(a1, T[k << q]);
+            const int o = ((j - k) << 1) + k;
+            D[lpad(o)] = a0 + a1; D[lpad(o + (1 << ls))] = a0 - a1;
+        }
+    }
+}
+// the passes of an N = 2^n transform: the odd radix (n mod 3 bits) first, radix 8 after it
+__device__ __forceinline__ int first_radix_log2(int n) { const int r = n % 3; return r ? r : 3; }
+
+// A batch of transforms, one per `slot`, all threads of the block passing through the same barriers. `active`: this thread works
+// on transform D (of N/8 threads, as number l); idle threads only keep the barrier count.
+template<int S, class TF> __device__ __forceinline__ void fft_batch(C2<TF>* D, const C2<TF>* T, int tshift, int l, int n, bool active)
+{
+    C2<TF> v[8];
+    int ls = 0;
+    for (int lr = first_radix_log2(n); ls < n; ls += lr, lr = 3)
+    {
+        if (active) fft_gather(D, l, n, v);
+        __syncthreads();
+        if (active) fft_scatter<S>(D, T, tshift, l, n, lr, ls, v);
+        __syncthreads();
+    }
+}
+
+// ======================================================================================================================
+// (1) Pres_2::input + the transform along x. Block = 8 rows j0..j0+7, marching up through KC levels; thread = column i.
+// ======================================================================================================================
+template<class TF>
+struct PresLdsIn
+{
+    GridDev<TF> g;
+    const TF* u; const TF* v; const TF* w; const TF* ut; const TF* vt; const TF* wt; const TF* rhoref; const TF* rhorefh;
+    TF dti;
+    C2<TF>* S; const C2<TF>* Tx;      // Tx[m] = exp(-2 pi i m / itot), m < itot
+    int nx;                           // log2(itot/2)
+    int kc;                           // levels per block
+};
+template<class TF, int RG>
+__global__ void __launch_bounds__(1024) pres_in_fftx_kernel(const PresLdsIn<TF> a)
+{
+    HIP_DYNAMIC_SHARED(double, lds_raw);
+    const GridDev<TF>& g = a.g;
+    const int itot = g.itot, jtot = g.jtot, nh = itot >> 1, rp = lpad(nh) + 2;
+    C2<TF>* D = reinterpret_cast<C2<TF>*>(lds_raw);
+    C2<TF>* T = D + 8*rp;
+    const int tid = threadIdx.x;                   // blockDim.x == itot
+    T[tid] = a.Tx[tid];
+    const int j0 = blockIdx.x*8, k0 = blockIdx.y*a.kc, k1 = (k0 + a.kc < g.kmax) ? k0 + a.kc : g.kmax;
+    const int jj = g.icells, kk = g.ijcells;
+    const int c0 = (tid + g.igc) + (j0 + g.jgc)*jj;
+    const int team = nh >> 3, slot = tid / team, l = tid - slot*team;     // the transform this thread works on in the passes
+    const bool active = slot < 8;
+    TF* Dr = reinterpret_cast<TF*>(D);
+    // the lower-face term of level k is the upper-face term of level k-1: carried
+    TF low[8];
+    {
+        const int c = c0 + (k0 + g.kgc)*kk; const TF rh = a.rhorefh[k0 + g.kgc];
+#pragma unroll
+        for (int r=0; r<8; ++r) low[r] = rh * (a.wt[c + r*jj] + a.w[c + r*jj] * a.dti);
+    }
+    for (int k=k0; k<k1; ++k)
+    {
+        const int kd = k + g.kgc, c = c0 + kd*kk;
+        const TF rk = a.rhoref[kd], rhp = a.rhorefh[kd+1], dzi = g.dzi[kd];
+#pragma unroll
+        for (int h=0; h<8; h+=RG)                     // RG rows at a time: the loads of a group in flight together
+        {
+            TF uc[RG], ue[RG], utc[RG], ute[RG], vv[RG+1], vvt[RG+1], wu[RG], wtu[RG];
+#pragma unroll
+            for (int r=0; r<RG; ++r)
+            {
+                const int cr = c + (h + r)*jj;
+                uc[r] = a.u[cr]; ue[r] = a.u[cr+1]; utc[r] = a.ut[cr]; ute[r] = a.ut[cr+1];
+                wu[r] = a.w[cr+kk]; wtu[r] = a.wt[cr+kk];
+            }
+#pragma unroll
+            for (int r=0; r<RG+1; ++r) { const int cr = c + (h + r)*jj; vv[r] = a.v[cr]; vvt[r] = a.vt[cr]; }
+#pragma unroll
+            for (int r=0; r<RG; ++r)
+            {
+                const TF up = rhp * (wtu[r] + wu[r] * a.dti);
+                // pres2_in (cell_ops.h), with the two vertical face terms named
+                const TF d = rk * ( (ute[r] + ue[r] * a.dti) - (utc[r] + uc[r] * a.dti) ) * g.dxi_t
+                           + rk * ( (vvt[r+1] + vv[r+1] * a.dti) - (vvt[r] + vv[r] * a.dti) ) * g.dyi_t
+                           + ( up - low[h + r] ) * dzi;
+                low[h + r] = up;
+                Dr[2*((h + r)*rp + lpad(tid >> 1)) + (tid & 1)] = d;
+            }
+            sched_fence();
+        }
+        __syncthreads();
+        fft_batch<-1>(D + (active ? slot : 0)*rp, T, 1, l, a.nx, active);
+        // real-to-complex: X[kx] = E + exp(-2 pi i kx / itot) O from Z[kx] and Z[nh - kx]; one (kx, row) element per thread and turn,
+        // rows fastest: eight neighbouring threads write one 128-byte (fp64) piece of S[k][kx][j0..j0+7]
+        for (int e=tid; e<8*nh; e+=itot)
+        {
+            const int kx = e >> 3, r = e & 7;
+            const C2<TF> za = D[r*rp + lpad(kx)], zb = D[r*rp + lpad((nh - kx) & (nh-1))];
+            const C2<TF> ev{TF(0.5)*(za.x + zb.x), TF(0.5)*(za.y - zb.y)};         // (Za + conj Zb) / 2
+            const C2<TF> od{TF(0.5)*(za.y + zb.y), TF(0.5)*(zb.x - za.x)};         // (Za - conj Zb) / (2 i)
+            C2<TF> x = ev + mul_tw<-1>(od, T[kx]);
+            if (kx == 0) x = C2<TF>{za.x + za.y, za.x - za.y};                      // (X_0, X_nyq): both real, one column
+            a.S[((size_t)k*nh + kx)*jtot + j0 + r] = x;
+        }
+        __syncthreads();
+    }
+}
+
+// ======================================================================================================================
+// (2) Transforms along y around the Thomas sweeps. Block = one kx; thread = one ky; eight levels per round.
+//
+// The modes kx = 0 and kx = itot/2 are real along x, so stage 1 stores them as ONE complex column, S[k][0][j] = (X_0, X_nyq):
+// itot/2 columns, a block each -- 256 blocks for 256 CUs at itot = 512 instead of 257. After the transform along y the two
+// Hermitian spectra are separated again (Y_0[ky] = (Z[ky] + conj Z[-ky]) / 2, Y_nyq[ky] = (Z[ky] - conj Z[-ky]) / 2i); thread
+// ky < N/2 of block 0 solves mode (0, ky), thread N - ky solves mode (itot/2, ky), and threads 0 and N/2 carry two REAL
+// modes, (0, ky) in the real and (itot/2, ky) in the imaginary part, each with its own pivots ("two").
+// ======================================================================================================================
+template<class TF>
+struct PresLdsSolve
+{
+    C2<TF>* S; const TF* W3;          // W3[k][kx][ky] = c[k-1] / w2[k-1] of the mode thread ky of block kx solves; row ncol: the second modes of "two"
+    const TF* bmati; const TF* bmatj; const TF* a; const TF* c; const TF* dz; const TF* rho;
+    const C2<TF>* Ty;                 // exp(-2 pi i m / jtot)
+    int ncol, jtot, ny, kmax;         // ncol = itot/2 columns; ny = log2(jtot)
+};
+// 1 / x: hardware seed + two Newton steps (the pivots are O(1): no scaling needed)
+template<class TF> __device__ __forceinline__ TF recip(TF x)
+{
+    TF y = recip_seed(x);
+    TF e = tfma(-x, y, TF(1)); y = tfma(y, e, y);
+    e = tfma(-x, y, TF(1));    y = tfma(y, e, y);
+    return y;
+}
+template<class TF>
+__device__ __forceinline__ TF tdma_diag_lds(const PresLdsSolve<TF>& a, TF bm, bool mean, int k)
+{
+    const TF dz2 = a.dz[k]*a.dz[k];
+    TF b = dz2 * a.rho[k]*bm - (a.a[k]+a.c[k]);
+    if (k == 0) b += a.a[0];
+    if (k == a.kmax-1) { if (mean) b -= a.c[k]; else b += a.c[k]; }
+    return b;
+}
+// which mode thread ky of block kx solves: its bmati index
+__device__ __forceinline__ int lds_mode_kx(int kx, int ky, int N, int ncol) { return (kx == 0 && ky > (N >> 1)) ? ncol : kx; }
+// the Thomas pivots (src/pres_2.cxx:213-249) as reciprocals: w3[k] = c[k-1] * (1 / w2[k-1]), the same recurrence in the factor
+// kernel (plan creation) and in the forward sweep, so that the two sweeps use one and the same factorisation
+template<class TF>
+__global__ void __launch_bounds__(64) pres_lds_factor_kernel(TF* __restrict__ W3, const PresLdsSolve<TF> a)
+{
+    const int ky = blockIdx.x*64 + threadIdx.x, row = blockIdx.y;          // rows 0 .. ncol
+    if (ky >= a.jtot) return;
+    const int kxa = (row == a.ncol) ? a.ncol : lds_mode_kx(row, ky, a.jtot, a.ncol);
+    const TF bm = a.bmati[kxa] + a.bmatj[ky];
+    const bool mean = (row == 0 && ky == 0);
+    const size_t col = (size_t)row*a.jtot + ky, lev = (size_t)(a.ncol + 1)*a.jtot;
+    TF inv = recip(tdma_diag_lds(a, bm, mean, 0));
+    W3[col] = TF(0);
+    for (int k=1; k<a.kmax; ++k)
+    {
+        const TF w3 = a.c[k-1] * inv;
+        W3[col + k*lev] = w3;
+        inv = recip(tdma_diag_lds(a, bm, mean, k) - a.a[k]*w3);
+    }
+}
+template<class TF, int BT>
+__global__ void __launch_bounds__(BT) pres_ysolve_kernel(const PresLdsSolve<TF> a)
+{
+    HIP_DYNAMIC_SHARED(double, lds_raw);
+    const int N = a.jtot, kmax = a.kmax, rp = lpad(N);
+    C2<TF>* D = reinterpret_cast<C2<TF>*>(lds_raw);
+    C2<TF>* T = D + 8*rp;
+    const int ky = threadIdx.x, kx = blockIdx.x;   // blockDim.x == jtot
+    T[ky] = a.Ty[ky];
+    const int team = N >> 3, slot = ky / team, l = ky - slot*team;        // slot < 8 always
+    const size_t lev = (size_t)a.ncol*N, wlev = (size_t)(a.ncol + 1)*N;
+    C2<TF>* Sc = a.S + (size_t)kx*N + ky;
+    const TF* Wc = a.W3 + (size_t)kx*N + ky;
+    const TF* Wc2 = a.W3 + (size_t)a.ncol*N + ky;
+    const bool packed = (kx == 0);
+    const bool two = packed && (ky == 0 || ky == (N >> 1));
+    const bool upper = ky > (N >> 1);
+    const int mir = (N - ky) & (N - 1);
+    const TF bm = a.bmati[lds_mode_kx(kx, ky, N, a.ncol)] + a.bmatj[ky];
+    const TF bm2 = a.bmati[a.ncol] + a.bmatj[ky];
+    const bool mean = (kx == 0 && ky == 0);
+    const int nround = (kmax + 7) >> 3;
+
+    // ---- down: rows of eight levels -> LDS -> transform along y -> forward sweep -> S (in place)
+    TF inv = TF(1), inv2 = TF(1); C2<TF> pp{TF(0), TF(0)};
+    C2<TF> q[8];
+#pragma unroll
+    for (int m=0; m<8; ++m) q[m] = (m < kmax) ? Sc[m*lev] : C2<TF>{TF(0), TF(0)};
+    for (int rd=0; rd<nround; ++rd)
+    {
+        const int k0 = rd << 3;
+#pragma unroll
+        for (int m=0; m<8; ++m) D[m*rp + lpad(ky)] = q[m];
+        if (rd + 1 < nround)
+        {
+#pragma unroll
+            for (int m=0; m<8; ++m) if (k0 + 8 + m < kmax) q[m] = Sc[(size_t)(k0 + 8 + m)*lev];
+        }
+        __syncthreads();
+        fft_batch<-1>(D + slot*rp, T, 0, l, a.ny, true);
+        C2<TF> r8[8];
+#pragma unroll
+        for (int m=0; m<8; ++m)
+        {
+            C2<TF> r = D[m*rp + lpad(ky)];
+            if (packed && !two)
+            {
+                const C2<TF> zm = D[m*rp + lpad(mir)];
+                r = upper ? C2<TF>{TF(0.5)*(zm.y + r.y), TF(0.5)*(r.x - zm.x)}       // Y_nyq[N-ky] = (Z[N-ky] - conj Z[ky]) / 2i
+                          : C2<TF>{TF(0.5)*(r.x + zm.x), TF(0.5)*(r.y - zm.y)};      // Y_0[ky]     = (Z[ky] + conj Z[N-ky]) / 2
+            }
+            r8[m] = r;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m=0; m<8; ++m)
+        {
+            const int k = k0 + m;
+            if (k < kmax)
+            {
+                const TF dz2 = a.dz[k]*a.dz[k];
+                TF w2 = tdma_diag_lds(a, bm, mean, k);
+                C2<TF> r = r8[m];
+                r.x = dz2 * r.x; r.y = dz2 * r.y;
+                if (k > 0)
+                {
+                    w2 -= a.a[k] * (a.c[k-1] * inv);
+                    r.x -= a.a[k]*pp.x; r.y -= a.a[k]*pp.y;
+                }
+                inv = recip(w2);
+                r.x *= inv;
+                if (two)
+                {
+                    TF w2b = tdma_diag_lds(a, bm2, false, k);
+                    if (k > 0) w2b -= a.a[k] * (a.c[k-1] * inv2);
+                    inv2 = recip(w2b);
+                    r.y *= inv2;
+                }
+                else r.y *= inv;
+                pp = r;
+                Sc[(size_t)k*lev] = r;
+            }
+        }
+    }
+    // ---- up: back substitution over eight levels -> LDS -> inverse transform along y -> S
+    // (the values this thread reads back are the ones it wrote itself)
+    TF w3[8], w3b[8];
+    {
+        const int k0 = (nround-1) << 3;
+#pragma unroll
+        for (int m=0; m<8; ++m)
+        {
+            w3[m] = TF(0); w3b[m] = TF(0);
+            if (k0 + m < kmax) q[m] = Sc[(size_t)(k0 + m)*lev];
+            if (k0 + m + 1 < kmax) { w3[m] = Wc[(size_t)(k0 + m + 1)*wlev]; if (two) w3b[m] = Wc2[(size_t)(k0 + m + 1)*wlev]; }
+        }
+    }
+    pp = C2<TF>{TF(0), TF(0)};            // the solution of the level above (nothing above the top level: w3 = 0 there)
+    for (int rd=nround-1; rd>=0; --rd)
+    {
+        const int k0 = rd << 3;
+#pragma unroll
+        for (int m=7; m>=0; --m)
+        {
+            const int k = k0 + m;
+            C2<TF> r{TF(0), TF(0)};
+            if (k < kmax)
+            {
+                r = q[m];
+                if (k < kmax-1) { r.x -= w3[m]*pp.x; r.y -= (two ? w3b[m] : w3[m])*pp.y; }
+                pp = r;
+            }
+            D[m*rp + lpad(ky)] = r;
+        }
+        if (rd > 0)
+        {
+#pragma unroll
+            for (int m=0; m<8; ++m)
+            {
+                q[m] = Sc[(size_t)(k0 - 8 + m)*lev]; w3[m] = Wc[(size_t)(k0 - 8 + m + 1)*wlev];
+                if (two) w3b[m] = Wc2[(size_t)(k0 - 8 + m + 1)*wlev];
+            }
+        }
+        __syncthreads();
+        if (packed)                        // Z[ky] = Y_0[ky] + i Y_nyq[ky] again, the upper half from the Hermitian symmetry of both
+        {
+            C2<TF> z[8];
+#pragma unroll
+            for (int m=0; m<8; ++m)
+            {
+                const C2<TF> own = D[m*rp + lpad(ky)], mv = D[m*rp + lpad(mir)];
+                z[m] = two ? own : (upper ? C2<TF>{mv.x + own.y, own.x - mv.y} : C2<TF>{own.x - mv.y, own.y + mv.x});
+            }
+            __syncthreads();
+#pragma unroll
+            for (int m=0; m<8; ++m) D[m*rp + lpad(ky)] = z[m];
+            __syncthreads();
+        }
+        fft_batch<+1>(D + slot*rp, T, 0, l, a.ny, true);
+#pragma unroll
+        for (int m=0; m<8; ++m) if (k0 + m < kmax) Sc[(size_t)(k0 + m)*lev] = D[m*rp + lpad(ky)];
+        __syncthreads();
+    }
+}
+
+// ======================================================================================================================
+// (3) The transform back along x + p + Pres_2::output. Block = rows j0-1 .. j0+7 (the first one only for the gradient in y),
+// marching up through KC levels (one level below them first, for the gradient in z); thread = column i.
+// ======================================================================================================================
+template<class TF>
+struct PresLdsOut
+{
+    GridDev<TF> g;
+    const C2<TF>* S; const C2<TF>* Tx;
+    TF* p; TF* ut; TF* vt; TF* wt;
+    int nx, kc;
+};
+template<class TF, int RG>
+__global__ void __launch_bounds__(1024) pres_ifftx_out_kernel(const PresLdsOut<TF> a)
+{
+    HIP_DYNAMIC_SHARED(double, lds_raw);
+    const GridDev<TF>& g = a.g;
+    const int itot = g.itot, jtot = g.jtot, nh = itot >> 1, rp = lpad(nh) + 2;
+    C2<TF>* D = reinterpret_cast<C2<TF>*>(lds_raw);       // row r+1 of the strip at D + (r+1)*rp; row 0 = j0-1
+    C2<TF>* T = D + 9*rp;
+    const int tid = threadIdx.x;                   // blockDim.x == itot
+    T[tid] = a.Tx[tid];
+    const int j0 = blockIdx.x*8, k0 = blockIdx.y*a.kc, k1 = (k0 + a.kc < g.kmax) ? k0 + a.kc : g.kmax;
+    const int jj = g.icells, kk = g.ijcells;
+    const int team = nh >> 3, slot = tid / team, l = tid - slot*team;
+    const bool active = slot < 9;
+    const TF* Dr = reinterpret_cast<const TF*>(D);
+    const TF nrm = (TF(1) / TF(jtot)) * (TF(1) / TF(itot));           // both powers of two: exact
+    const int jsouth = (j0 + jtot - 1) & (jtot - 1);
+    const int iw = (tid + itot - 1) & (itot - 1);
+    TF below[8];
+#pragma unroll
+    for (int r=0; r<8; ++r) below[r] = TF(0);
+    for (int k = (k0 > 0 ? k0-1 : 0); k<k1; ++k)
+    {
+        const bool emit = (k >= k0);
+        const int c = (tid + g.igc) + (j0 + g.jgc)*jj + (k + g.kgc)*kk;
+        // spectral rows -> LDS (columns 0 .. nh-1, column 0 = (X_0, X_nyq); rows fastest in memory)
+        for (int e=tid; e<9*nh; e+=itot)
+        {
+            const int kx = e / 9, r = e - 9*kx;
+            const int j = (r == 0) ? jsouth : j0 + r - 1;
+            D[r*rp + lpad(kx)] = a.S[((size_t)k*nh + kx)*jtot + j];
+        }
+        __syncthreads();
+        // complex-to-real: Z[kx] = (Xa + conj Xb) + i (Xa - conj Xb) exp(+2 pi i kx / itot), Xb = X[nh - kx]; pairs (kx, nh - kx) in place
+        for (int e=tid; e<9*(nh/2 + 1); e+=itot)
+        {
+            const int r = e / (nh/2 + 1), kx = e - r*(nh/2 + 1), kb = nh - kx;
+            const C2<TF> xa = D[r*rp + lpad(kx)], xb = D[r*rp + lpad(kb & (nh-1))];
+            if (kx == 0) D[r*rp] = C2<TF>{xa.x + xa.y, xa.x - xa.y};                // X_0 and X_nyq are real: Z[0] = (X_0 + X_nyq) + i (X_0 - X_nyq)
+            else
+            {
+                const C2<TF> ev{xa.x + xb.x, xa.y - xb.y}, df{xa.x - xb.x, xa.y + xb.y};
+                const C2<TF> od = mul_tw<+1>(df, T[kx]);
+                D[r*rp + lpad(kx)] = C2<TF>{ev.x - od.y, ev.y + od.x};
+            }
+            if (kx != 0 && kb != kx)
+            {
+                const C2<TF> ev{xb.x + xa.x, xb.y - xa.y}, df{xb.x - xa.x, xb.y + xa.y};
+                const C2<TF> od = mul_tw<+1>(df, T[kb]);
+                D[r*rp + lpad(kb)] = C2<TF>{ev.x - od.y, ev.y + od.x};
+            }
+        }
+        __syncthreads();
+        fft_batch<+1>(D + (active ? slot : 0)*rp, T, 1, l, a.nx, active);
+        // rows of p: element i of row r at real index 2*lpad(i/2) + (i&1)
+        const int oc = 2*lpad(tid >> 1) + (tid & 1), ow = 2*lpad(iw >> 1) + (iw & 1);
+        TF ps = Dr[2*(0*rp) + oc] * nrm;
+#pragma unroll
+        for (int h=0; h<8; h+=RG)
+        {
+            TF tu[RG], tv[RG], tw[RG];
+            if (emit)
+            {
+#pragma unroll
+                for (int r=0; r<RG; ++r) { tu[r] = a.ut[c + (h+r)*jj]; tv[r] = a.vt[c + (h+r)*jj]; tw[r] = a.wt[c + (h+r)*jj]; }
+            }
+#pragma unroll
+            for (int q=0; q<RG; ++q)
+            {
+                const int r = h + q;
+                const TF pc = Dr[2*((r+1)*rp) + oc] * nrm, pw = Dr[2*((r+1)*rp) + ow] * nrm;
+                if (emit)
+                {
+                    const int cr = c + r*jj;
+                    const TF pb = (k == 0) ? pc : below[r];                          // p[kstart-1] = p[kstart]
+                    a.ut[cr] = tu[q] - (pc - pw) * g.dxi_t;
+                    a.vt[cr] = tv[q] - (pc - ps) * g.dyi_t;
+                    a.wt[cr] = tw[q] - (pc - pb) * g.dzhi[k + g.kgc];
+                    // p: the cell, its images in the periodic halo, and the ghost level below the first one
+                    const int js = j0 + r;
+                    for (int lv=0; lv<2; ++lv)
+                    {
+                        if (lv == 1 && k != 0) break;
+                        const int cl = cr - lv*kk;
+                        for (int rowsel=0; rowsel<3; ++rowsel)
+                        {
+                            int off;
+                            if (rowsel == 0) off = 0;
+                            else if (rowsel == 1) { if (js < jtot - g.jgc) continue; off = -jtot*jj; }     // row js - jtot: the south halo
+                            else                  { if (js >= g.jgc) continue;       off =  jtot*jj; }     // row js + jtot: the north halo
+                            a.p[cl + off] = pc;
+                            if (tid >= itot - g.igc) a.p[cl + off - itot] = pc;
+                            if (tid < g.igc)         a.p[cl + off + itot] = pc;
+                        }
+                    }
+                }
+                below[r] = pc; ps = pc;
+            }
+            sched_fence();
+        }
+        __syncthreads();
+    }
+}
+
+}} // namespace mhh::lds_fft

@@ -41,6 +41,11 @@ class EmulBackend:
     def grid(self, g):
         return g.host_struct()
 
+    def view(self, p, shape, dtype):
+        """An array over `device` memory the library owns (address p)."""
+        ct = C.c_double if np.dtype(dtype) == np.float64 else C.c_float
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=shape)
+
     def sync(self):
         pass
 
@@ -73,6 +78,15 @@ class HipBackend:
 
     def grid(self, g):
         return g.device_struct(self.dev)
+
+    def view(self, p, shape, dtype):
+        """A copy (device to device) of memory the library owns (address p)."""
+        out = self.zeros(shape, dtype)
+        self.torch.cuda.synchronize()
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        assert hip.hipMemcpy(out.data_ptr(), p, out.numel()*out.element_size(), 3) == 0
+        return out
 
     def sync(self):
         self.torch.cuda.synchronize()

@@ -8,3 +8,4 @@ extern "C" void emul_fiber_entry()
     g_emul.body();
     g_emul.cur->done = true;     // returning switches to uc_link = the scheduler
 }
+alignas(64) double g_emul_dyn_lds[160*1024/8];

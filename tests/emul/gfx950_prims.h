@@ -26,6 +26,8 @@ template<int PB> inline void lds_dma_sv(const void*, unsigned, unsigned) {}
 template<int PB> inline void lds_dma_sv2(const void*, unsigned, unsigned, unsigned) {}
 template<class T> inline T sgpr(T x) { return x; }
 inline void sched_fence() {}
+inline double recip_seed(double x) { return 1./x; }
+inline float  recip_seed(float x)  { return 1.f/x; }
 inline void keep_vgpr(unsigned&) {}
 template<class T> inline T gload(const T* b, unsigned o) { return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(b) + o); }
 template<class T> inline T gload_stream(const T* b, unsigned o) { return gload(b, o); }

@@ -32,6 +32,11 @@ inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { m
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? 0 : 2; }
 inline hipError_t hipFree(void* p) { free(p); return 0; }
+// dynamic LDS: one buffer of a CU's 160 KB (blocks run one at a time)
+extern double g_emul_dyn_lds[160*1024/8];
+#define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(g_emul_dyn_lds);
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize };
+inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return 0; }
 
 // Execution model: every simulated thread of a block is a fiber (ucontext). A fiber runs until it finishes or
 // reaches __syncthreads(), which yields to the scheduler; the scheduler resumes the block's fibers round-robin,

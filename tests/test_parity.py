@@ -376,10 +376,11 @@ def test_pres_exec_callback_fused_equals_staged(be, order, dtype):
             plan = capi.PLAN()
             B.ok(be, be.lib.mhh_pres_plan_create(Gh, order, ptr(g.dz), ptr(g.dzhi), ptr(g.dzi4), ptr(g.dzhi4), ptr(c.rhoref), ptr(c.rhorefh), C.byref(plan)))
             os.environ["MHH_PRES_FUSED"] = "1" if form == "fused" else "0"
+            os.environ["MHH_PRES_LDS"] = "0"                     # both are forms of the rocFFT path
             try:
                 B.ok(be, be.lib.mhh_pres_exec(plan, d.G, C.byref(f), dt, be.stream))
             finally:
-                os.environ.pop("MHH_PRES_FUSED", None)
+                os.environ.pop("MHH_PRES_FUSED", None); os.environ.pop("MHH_PRES_LDS", None)
             out[form] = [be.host(x) for x in (d.p, d.ut, d.vt, d.wt)]
             be.lib.mhh_pres_plan_destroy(plan)
         for a, b, nm in zip(out["fused"], out["staged"], ("p", "ut", "vt", "wt")):
@@ -455,15 +456,77 @@ def test_pres2_exec_unpack_and_output_in_one_kernel_equals_two(be, dtype):
             B.ok(be, be.lib.mhh_pres_plan_create(Gh, 2, ptr(g.dz), ptr(g.dzhi), ptr(g.dzi4), ptr(g.dzhi4), ptr(c.rhoref), ptr(c.rhorefh), C.byref(plan)))
             if form == "two":
                 os.environ["MHH_PRES_UNPACK_OUT"] = "0"
+            os.environ["MHH_PRES_LDS"] = "0"                     # both are forms of the rocFFT path
             try:
                 B.ok(be, be.lib.mhh_pres_exec(plan, d.G, C.byref(f), dt, be.stream))
             finally:
-                os.environ.pop("MHH_PRES_UNPACK_OUT", None)
+                os.environ.pop("MHH_PRES_UNPACK_OUT", None); os.environ.pop("MHH_PRES_LDS", None)
             out[form] = [be.host(x) for x in (d.p, d.ut, d.vt, d.wt)]
             be.lib.mhh_pres_plan_destroy(plan)
         for x, y, nm in zip(out["one"], out["two"], ("p", "ut", "vt", "wt")):
             assert same(x, y), (g.shape3, nm, cm.ulp_diff(x, y))
         assert not np.array_equal(out["one"][1], c.ut)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pres2_lds_transform_form(be, dtype):
+    """Pres_2::exec as three kernels with the transforms in LDS (csrc/pres_lds.h; power-of-two itot, jtot -- the form
+    mhh_pres_exec takes by default there). Stage 1 against numpy's real transform of the oracle's Pres_2::input (the modes
+    kx = 0 and kx = itot/2 share column 0); the whole operator against the oracle's input -> solve -> output: p with all its
+    ghost cells and the three corrected tendencies within the pressure tolerance; levels-per-block that do and do not divide
+    kmax; the ghost-cell side effects of Pres_2::input on ut, vt bit for bit."""
+    O = cm.oracle()
+    tol = 1e-11 if dtype == np.float64 else 2e-4
+    cases = [((16, 8, 6), (2, 2, 1), None), ((32, 16, 10), (3, 3, 1), "3"), ((64, 8, 9), (1, 1, 1), "4"), ((16, 64, 17), (3, 3, 1), None), ((128, 32, 5), (3, 3, 2), "2")]
+    for shape, gc, kc in cases:
+        g = cm.grid_2nd(*shape, gc=gc, dtype=dtype)
+        c = cm.Case(g, rho="random", periodic=True); Gh = g.host_struct(); dt = 0.7
+        d = B.DevCase(be, c); f = d.fields()
+        plan = capi.PLAN()
+        B.ok(be, be.lib.mhh_pres_plan_create(Gh, 2, ptr(g.dz), ptr(g.dzhi), ptr(g.dzi4), ptr(g.dzhi4), ptr(c.rhoref), ptr(c.rhorefh), C.byref(plan)))
+        if kc: os.environ["MHH_PRES_LDS_KC"] = kc
+        try:
+            assert be.lib.mhh_pres_plan_has_lds_form(plan) == 1
+            pk_want = np.zeros((g.ktot, g.jtot, g.itot), dtype=dtype)
+            ut, vt, wt = c.ut.copy(), c.vt.copy(), c.wt.copy()
+            O.orc_pres_input(Gh, 2, ptr(pk_want), ptr(c.u), ptr(c.v), ptr(c.w), ptr(ut), ptr(vt), ptr(wt), ptr(c.rhoref), ptr(c.rhorefh), dbl(dt))
+            B.ok(be, be.lib.mhh_pres_lds_stage(plan, d.G, C.byref(f), dt, 1, be.stream)); be.sync()
+            assert same(be.host(d.ut), ut) and same(be.host(d.vt), vt)
+            nh = g.itot // 2
+            spec = be.host(be.view(be.lib.mhh_pres_plan_spectral(plan), (g.ktot, nh, g.jtot, 2), dtype))
+            want = np.fft.rfft(pk_want.astype(np.float64), axis=2).transpose(0, 2, 1)
+            got = spec[..., 0] + 1j*spec[..., 1]
+            scale = np.abs(want).max()
+            assert np.abs(got[:, 1:] - want[:, 1:nh]).max() <= tol*scale
+            assert np.abs(got[:, 0].real - want[:, 0].real).max() <= tol*scale and np.abs(got[:, 0].imag - want[:, nh].real).max() <= tol*scale
+            B.ok(be, be.lib.mhh_pres_lds_stage(plan, d.G, C.byref(f), dt, 2, be.stream))
+            B.ok(be, be.lib.mhh_pres_lds_stage(plan, d.G, C.byref(f), dt, 3, be.stream))
+            p_want = np.zeros(g.shape3, dtype=dtype); pk_tmp = pk_want.copy()
+            O.orc_pres_solve(Gh, 2, ptr(p_want), ptr(pk_tmp), ptr(c.rhoref), ptr(c.rhorefh))
+            O.orc_pres_output(Gh, 2, ptr(ut), ptr(vt), ptr(wt), ptr(p_want))
+            sl = (slice(g.kstart-1, g.kend), slice(None), slice(None))
+            pscale = np.abs(p_want).max()
+            assert np.abs(be.host(d.p)[sl] - p_want[sl]).max() <= tol*pscale, (shape, np.abs(be.host(d.p)[sl] - p_want[sl]).max()/pscale)
+            for got_t, want_t, nm in ((d.ut, ut, "ut"), (d.vt, vt, "vt"), (d.wt, wt, "wt")):
+                assert np.abs(be.host(got_t) - want_t).max() <= tol*max(np.abs(want_t).max(), pscale/float(min(g.dx, g.dy))), (shape, nm)
+            # mhh_pres_exec takes this form by itself: same bits as the three stages
+            d2 = B.DevCase(be, c); f2 = d2.fields()
+            B.ok(be, be.lib.mhh_pres_exec(plan, d2.G, C.byref(f2), dt, be.stream))
+            for x, y in ((d.p, d2.p), (d.ut, d2.ut), (d.vt, d2.vt), (d.wt, d2.wt)):
+                assert same(be.host(x), be.host(y))
+            # and it is a projection: nothing left for a second solve
+            pk = be.zeros((g.ktot, g.jtot, g.itot), dtype)
+            B.ok(be, be.lib.mhh_pres_input(plan, d2.G, C.byref(f2), dt, be.ptr(pk), be.stream))
+            assert np.abs(be.host(pk)).max() <= (1e-9 if dtype == np.float64 else 2e-2) * np.abs(pk_want).max()
+        finally:
+            os.environ.pop("MHH_PRES_LDS_KC", None)
+            be.lib.mhh_pres_plan_destroy(plan)
+    # grids the form does not cover keep the staged one
+    g = cm.grid_2nd(12, 10, 8, gc=(3, 3, 1), dtype=dtype); c = cm.Case(g, rho="random", periodic=True)
+    plan = capi.PLAN()
+    B.ok(be, be.lib.mhh_pres_plan_create(g.host_struct(), 2, ptr(g.dz), ptr(g.dzhi), ptr(g.dzi4), ptr(g.dzhi4), ptr(c.rhoref), ptr(c.rhorefh), C.byref(plan)))
+    assert be.lib.mhh_pres_plan_has_lds_form(plan) == 0
+    be.lib.mhh_pres_plan_destroy(plan)
 
 
 @pytest.mark.parametrize("adv,dif", [(cm.ADVEC_2I4, cm.DIFF_2), (cm.ADVEC_2I62, cm.DIFF_SMAG2), (cm.ADVEC_2I53, cm.DIFF_SMAG2), (cm.ADVEC_4M, cm.DIFF_4)])
