@@ -154,6 +154,14 @@ template<class T> __device__ __forceinline__ void gstore_stream(T* uniform_base,
 }
 // Opaque re-definition of a per-lane value (no instruction): what is computed from it cannot be hoisted above this point.
 __device__ __forceinline__ void keep_vgpr(unsigned& x) { asm volatile("" : "+v"(x)); }
+// Orders the LDS traffic of ONE wave: what its lanes wrote before this point is what its lanes read after it. The LDS serves a
+// wave's instructions in order, so no s_barrier is involved -- the fence only keeps the compiler from moving accesses across.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 // v_rcp_f64 / v_rcp_f32: the hardware's reciprocal seed (refined by the caller)
 __device__ __forceinline__ double recip_seed(double x) { return __builtin_amdgcn_rcp(x); }
 __device__ __forceinline__ float  recip_seed(float x)  { return __builtin_amdgcn_rcpf(x); }

@@ -879,7 +879,10 @@ static int pres_exec_fused(mhh_pres_plan* P, const mhh_grid* g, const mhh_fields
 #ifndef MHH_PRES_LDS_RG
 #define MHH_PRES_LDS_RG 2          // rows whose loads a thread of the x-stage kernels keeps in flight together
 #endif
-static constexpr int LDS_RG = MHH_PRES_LDS_RG;
+#ifndef MHH_PRES_LDS_BT
+#define MHH_PRES_LDS_BT 1024       // largest block (= itot) of the x-stage kernels: bounds their registers
+#endif
+static constexpr int LDS_RG = MHH_PRES_LDS_RG, LDS_BT = MHH_PRES_LDS_BT;
 static int ilog2(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
 static size_t lds_bytes_x(const mhh_pres_plan* P, int rows) { return ((size_t)rows*(lds_fft::lpad(P->itot/2) + 2) + P->itot) * 2*P->esz; }
 static size_t lds_bytes_y(const mhh_pres_plan* P)           { return ((size_t)8*lds_fft::lpad(P->jtot) + P->jtot) * 2*P->esz; }
@@ -907,16 +910,16 @@ static int pres_lds_setup_t(mhh_pres_plan* P)
     hipLaunchKernelGGL(lds_fft::pres_lds_factor_kernel<TF>, dim3((P->jtot + 63)/64, P->itot/2 + 1), dim3(64), 0, 0, static_cast<TF*>(P->w3l), lds_solve_args<TF>(P));
     MHH_LAUNCH_CHECK();
     MHH_HIP_TRY(hipStreamSynchronize(0));
-    MHH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_fft::pres_in_fftx_kernel<TF, LDS_RG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_x(P, 8)));
+    MHH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_fft::pres_in_fftx_kernel<TF, LDS_RG, LDS_BT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_x(P, 8)));
     MHH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_fft::pres_ysolve_kernel<TF, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_y(P)));
     MHH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_fft::pres_ysolve_kernel<TF, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_y(P)));
-    MHH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_fft::pres_ifftx_out_kernel<TF, LDS_RG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_x(P, 9)));
+    MHH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_fft::pres_ifftx_out_kernel<TF, LDS_RG, LDS_BT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_x(P, 9)));
     return MHH_OK;
 }
 static int pres_lds_setup(mhh_pres_plan* P, const mhh_grid* g)
 {
     const size_t lds_max = 160*1024;
-    if (!(is_pow2(P->itot) && P->itot >= 16 && P->itot <= 1024 && is_pow2(P->jtot) && P->jtot >= 8 && P->jtot <= 1024)) return MHH_OK;
+    if (!(is_pow2(P->itot) && P->itot >= 16 && P->itot <= LDS_BT && is_pow2(P->jtot) && P->jtot >= 8 && P->jtot <= 1024)) return MHH_OK;
     if (lds_bytes_x(P, 9) > lds_max || lds_bytes_y(P) > lds_max) return MHH_OK;
     if (g->igc > P->itot || g->jgc > P->jtot) return MHH_OK;
     if (int e = (P->dtype == MHH_F64) ? pres_lds_setup_t<double>(P) : pres_lds_setup_t<float>(P)) return e;
@@ -925,8 +928,10 @@ static int pres_lds_setup(mhh_pres_plan* P, const mhh_grid* g)
 }
 static int lds_levels_per_block(const mhh_pres_plan* P)
 {
+    // enough blocks to fill the chip several times over (8 rows x kc levels each); every block re-does one level below its own
     const char* e = getenv("MHH_PRES_LDS_KC");
-    const int kc = e ? atoi(e) : 32;
+    int kc = e ? atoi(e) : (int)(((long long)P->ktot * (P->jtot/8)) / 2048);
+    if (!e) kc = kc < 4 ? 4 : (kc > 32 ? 32 : kc);
     return kc < 1 ? 1 : (kc > P->ktot ? P->ktot : kc);
 }
 // the three stages, also callable one by one (tests): 1 = input + x transform, 2 = y transforms + Thomas, 3 = x transform + p + output
@@ -946,7 +951,7 @@ MHH_API int mhh_pres_lds_stage(mhh_pres_plan* P, const mhh_grid* g, const mhh_fi
         if (int e = pres_input_halos(g, 2, f, stream)) return e;
 #define CALL(TF) [&]{ lds_fft::PresLdsIn<TF> a{make_grid<TF>(g), cp<TF>(f->u), cp<TF>(f->v), cp<TF>(f->w), cp<TF>(f->ut), cp<TF>(f->vt), cp<TF>(f->wt), \
                           cp<TF>(f->rhoref), cp<TF>(f->rhorefh), TF(1.)/TF(dt), static_cast<C2<TF>*>(P->spec), static_cast<const C2<TF>*>(P->tx), ilog2(P->itot/2), kc}; \
-                      hipLaunchKernelGGL((lds_fft::pres_in_fftx_kernel<TF, LDS_RG>), xgrid, dim3(P->itot), lds_bytes_x(P, 8), st, a); return MHH_OK; }()
+                      hipLaunchKernelGGL((lds_fft::pres_in_fftx_kernel<TF, LDS_RG, LDS_BT>), xgrid, dim3(P->itot), lds_bytes_x(P, 8), st, a); return MHH_OK; }()
         if (int e = MHH_DISPATCH(g, CALL)) return e;
 #undef CALL
     }
@@ -962,14 +967,14 @@ MHH_API int mhh_pres_lds_stage(mhh_pres_plan* P, const mhh_grid* g, const mhh_fi
         MHH_REQUIRE(f && f->p && f->ut && f->vt && f->wt, "null field");
 #define CALL(TF) [&]{ lds_fft::PresLdsOut<TF> a{make_grid<TF>(g), static_cast<const C2<TF>*>(P->spec), static_cast<const C2<TF>*>(P->tx), \
                           mp<TF>(f->p), mp<TF>(f->ut), mp<TF>(f->vt), mp<TF>(f->wt), ilog2(P->itot/2), kc}; \
-                      hipLaunchKernelGGL((lds_fft::pres_ifftx_out_kernel<TF, LDS_RG>), xgrid, dim3(P->itot), lds_bytes_x(P, 9), st, a); return MHH_OK; }()
+                      hipLaunchKernelGGL((lds_fft::pres_ifftx_out_kernel<TF, LDS_RG, LDS_BT>), xgrid, dim3(P->itot), lds_bytes_x(P, 9), st, a); return MHH_OK; }()
         if (int e = MHH_DISPATCH(g, CALL)) return e;
 #undef CALL
     }
     MHH_LAUNCH_CHECK();
     return MHH_OK;
 }
-// 1 if the plan can run (and mhh_pres_exec will by default run) the LDS-transform form
+// 1 if the plan can run the LDS-transform form (mhh_pres_exec takes it by itself on large grids, see there)
 MHH_API int mhh_pres_plan_has_lds_form(const mhh_pres_plan* P) { return (P && P->lds_ok) ? 1 : 0; }
 // the spectral array between the stages (tests): S[k][kx][j], complex
 MHH_API void* mhh_pres_plan_spectral(mhh_pres_plan* P) { return P ? P->spec : nullptr; }
@@ -980,8 +985,12 @@ MHH_API int mhh_pres_exec(mhh_pres_plan* P, const mhh_grid* g, const mhh_fields*
     // Opt-in (MHH_PRES_FUSED=1). Measured on MI355X: identical bits, but the transforms run the heavy producer through an
     // indirect call per element and lose more than the two saved array passes give back (512^3: 15.7 ms vs 14.7 ms per step;
     // 512x256x256 pres_4: 4.05 vs 3.42 ms), so the staged form stays the default.
-    const char* le = getenv("MHH_PRES_LDS");                                  // "0": the staged form also where the LDS form exists
-    if (P->lds_ok && !(le && !strcmp(le, "0")))
+    // The LDS form pays where the arrays are far larger than the caches and there is a block per CU for the y stage (measured on
+    // MI355X: 512^3 fp64 5.8 -> 5.0 ms, 1024 x 1024 x 256 fp32 7.9 -> 5.0 ms; 256^3 0.78 -> 0.92 ms, so not there).
+    // MHH_PRES_LDS=0 / 1: never / wherever the plan has the form.
+    const char* le = getenv("MHH_PRES_LDS");
+    const bool lds_large = (long long)P->itot*P->jtot*P->ktot >= (1ll << 26) && P->itot >= 512;
+    if (P->lds_ok && (le ? !strcmp(le, "1") : lds_large))
     {
         for (int stage=1; stage<=3; ++stage) if (int e = mhh_pres_lds_stage(P, g, f, dt, stage, stream)) return e;
         return MHH_OK;

@@ -24,6 +24,17 @@ namespace mhh { namespace lds_fft {
 template<class TF> __device__ __forceinline__ C2<TF> operator+(C2<TF> a, C2<TF> b) { return C2<TF>{a.x + b.x, a.y + b.y}; }
 template<class TF> __device__ __forceinline__ C2<TF> operator-(C2<TF> a, C2<TF> b) { return C2<TF>{a.x - b.x, a.y - b.y}; }
 
+// a complex number through uniform base + 32-bit byte offset (gload, gfx950_prims.h), as one 8- / 16-byte access
+template<class TF> __device__ __forceinline__ C2<TF> gload_c2(const C2<TF>* base, unsigned off)
+{
+#if defined(__clang__)
+    typedef TF pair_t __attribute__((ext_vector_type(2)));
+    const pair_t t = gload(reinterpret_cast<const pair_t*>(base), off);
+    return C2<TF>{t.x, t.y};
+#else
+    return gload(base, off);
+#endif
+}
 // one complex number in eight falls on a new 128-byte bank row: strided passes stay conflict-free
 __host__ __device__ __forceinline__ int lpad(int i) { return i + (i >> 3); }
 
@@ -106,18 +117,21 @@ template<int S, class TF> __device__ __forceinline__ void fft_scatter(C2<TF>* D,
 // the passes of an N = 2^n transform: the odd radix (n mod 3 bits) first, radix 8 after it
 __device__ __forceinline__ int first_radix_log2(int n) { const int r = n % 3; return r ? r : 3; }
 
-// A batch of transforms, one per `slot`, all threads of the block passing through the same barriers. `active`: this thread works
-// on transform D (of N/8 threads, as number l); idle threads only keep the barrier count.
-template<int S, class TF> __device__ __forceinline__ void fft_batch(C2<TF>* D, const C2<TF>* T, int tshift, int l, int n, bool active)
+// A batch of transforms, one per `slot`, all threads of the block passing through the same synchronisation points. `active`: this
+// thread works on transform D (of N/8 threads, as number l); idle threads only keep the count. WL: the N/8 threads of a transform
+// sit in one wave (N <= 512), so the passes need no block barrier at all -- the caller's barrier before (data in LDS) and after
+// (before other waves read the result) are the only ones.
+template<bool WL> __device__ __forceinline__ void fft_sync() { if (WL) wave_sync(); else __syncthreads(); }
+template<int S, bool WL, class TF> __device__ __forceinline__ void fft_batch(C2<TF>* D, const C2<TF>* T, int tshift, int l, int n, bool active)
 {
     C2<TF> v[8];
     int ls = 0;
     for (int lr = first_radix_log2(n); ls < n; ls += lr, lr = 3)
     {
         if (active) fft_gather(D, l, n, v);
-        __syncthreads();
+        fft_sync<WL>();
         if (active) fft_scatter<S>(D, T, tshift, l, n, lr, ls, v);
-        __syncthreads();
+        fft_sync<WL>();
     }
 }
 
@@ -134,8 +148,8 @@ struct PresLdsIn
     int nx;                           // log2(itot/2)
     int kc;                           // levels per block
 };
-template<class TF, int RG>
-__global__ void __launch_bounds__(1024) pres_in_fftx_kernel(const PresLdsIn<TF> a)
+template<class TF, int RG, int BT>
+__global__ void __launch_bounds__(BT) pres_in_fftx_kernel(const PresLdsIn<TF> a)
 {
     HIP_DYNAMIC_SHARED(double, lds_raw);
     const GridDev<TF>& g = a.g;
@@ -188,7 +202,8 @@ __global__ void __launch_bounds__(1024) pres_in_fftx_kernel(const PresLdsIn<TF> 
             sched_fence();
         }
         __syncthreads();
-        fft_batch<-1>(D + (active ? slot : 0)*rp, T, 1, l, a.nx, active);
+        fft_batch<-1, true>(D + (active ? slot : 0)*rp, T, 1, l, a.nx, active);
+        __syncthreads();
         // real-to-complex: X[kx] = E + exp(-2 pi i kx / itot) O from Z[kx] and Z[nh - kx]; one (kx, row) element per thread and turn,
         // rows fastest: eight neighbouring threads write one 128-byte (fp64) piece of S[k][kx][j0..j0+7]
         for (int e=tid; e<8*nh; e+=itot)
@@ -300,7 +315,8 @@ __global__ void __launch_bounds__(BT) pres_ysolve_kernel(const PresLdsSolve<TF> 
             for (int m=0; m<8; ++m) if (k0 + 8 + m < kmax) q[m] = Sc[(size_t)(k0 + 8 + m)*lev];
         }
         __syncthreads();
-        fft_batch<-1>(D + slot*rp, T, 0, l, a.ny, true);
+        fft_batch<-1, (BT <= 512)>(D + slot*rp, T, 0, l, a.ny, true);
+        if (BT <= 512) __syncthreads();
         C2<TF> r8[8];
 #pragma unroll
         for (int m=0; m<8; ++m)
@@ -399,7 +415,8 @@ __global__ void __launch_bounds__(BT) pres_ysolve_kernel(const PresLdsSolve<TF> 
             for (int m=0; m<8; ++m) D[m*rp + lpad(ky)] = z[m];
             __syncthreads();
         }
-        fft_batch<+1>(D + slot*rp, T, 0, l, a.ny, true);
+        fft_batch<+1, (BT <= 512)>(D + slot*rp, T, 0, l, a.ny, true);
+        if (BT <= 512) __syncthreads();
 #pragma unroll
         for (int m=0; m<8; ++m) if (k0 + m < kmax) Sc[(size_t)(k0 + m)*lev] = D[m*rp + lpad(ky)];
         __syncthreads();
@@ -418,8 +435,8 @@ struct PresLdsOut
     TF* p; TF* ut; TF* vt; TF* wt;
     int nx, kc;
 };
-template<class TF, int RG>
-__global__ void __launch_bounds__(1024) pres_ifftx_out_kernel(const PresLdsOut<TF> a)
+template<class TF, int RG, int BT>
+__global__ void __launch_bounds__(BT) pres_ifftx_out_kernel(const PresLdsOut<TF> a)
 {
     HIP_DYNAMIC_SHARED(double, lds_raw);
     const GridDev<TF>& g = a.g;
@@ -471,7 +488,8 @@ __global__ void __launch_bounds__(1024) pres_ifftx_out_kernel(const PresLdsOut<T
             }
         }
         __syncthreads();
-        fft_batch<+1>(D + (active ? slot : 0)*rp, T, 1, l, a.nx, active);
+        fft_batch<+1, true>(D + (active ? slot : 0)*rp, T, 1, l, a.nx, active);
+        __syncthreads();
         // rows of p: element i of row r at real index 2*lpad(i/2) + (i&1)
         const int oc = 2*lpad(tid >> 1) + (tid & 1), ow = 2*lpad(iw >> 1) + (iw & 1);
         TF ps = Dr[2*(0*rp) + oc] * nrm;

@@ -99,6 +99,35 @@ def test_pressure_step_is_a_projection_at_full_size(case, shape):
     hp.close()
 
 
+@pytest.mark.parametrize("case,shape,tol", [("drycblles", (512, 512, 512), 1e-11), ("gabls1", (1024, 1024, 256), 2e-4)],
+                         ids=["configs3-drycblles512-fp64", "configs4-gabls1-fp32"])
+def test_pressure_lds_transform_form_matches_staged_form_at_full_size(case, shape, tol):
+    """Pres_2::exec with the transforms in LDS (three kernels, the form mhh_pres_exec takes by itself at these sizes) against the
+    staged rocFFT form on the same right-hand side: p and the corrected tendencies within the pressure tolerance."""
+    import torch
+    hp = _hp(case, shape, dt=0.5)
+    assert hp.lib.mhh_pres_plan_has_lds_form(hp.plan) == 1
+    hp.cyclic_prognostic(); hp.exec_viscosity(); hp.rhs(); hp.sync()
+    keep = [t.clone() for t in (hp.ut, hp.vt, hp.wt)]
+    out = {}
+    for form in ("staged", "default"):
+        for t, k in zip((hp.ut, hp.vt, hp.wt), keep):
+            t.copy_(k)
+        hp.p.zero_()
+        if form == "staged":
+            os.environ["MHH_PRES_LDS"] = "0"
+        try:
+            hp.pres(); hp.sync()
+        finally:
+            os.environ.pop("MHH_PRES_LDS", None)
+        out[form] = [t.clone() for t in (hp.p, hp.ut, hp.vt, hp.wt)]
+    del keep
+    assert not torch.equal(out["staged"][0], out["default"][0])          # two different sets of transforms
+    for a, b, n in zip(out["staged"], out["default"], ("p", "ut", "vt", "wt")):
+        assert float((a - b).abs().max()) <= tol * float(a.abs().max()), (n, float((a - b).abs().max()) / float(a.abs().max()))
+    hp.close()
+
+
 def test_cyclic_fill_is_idempotent_and_periodic_at_full_size():
     import torch
     hp = _hp("drycblles", (256, 256, 256))

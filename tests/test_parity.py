@@ -509,9 +509,13 @@ def test_pres2_lds_transform_form(be, dtype):
             assert np.abs(be.host(d.p)[sl] - p_want[sl]).max() <= tol*pscale, (shape, np.abs(be.host(d.p)[sl] - p_want[sl]).max()/pscale)
             for got_t, want_t, nm in ((d.ut, ut, "ut"), (d.vt, vt, "vt"), (d.wt, wt, "wt")):
                 assert np.abs(be.host(got_t) - want_t).max() <= tol*max(np.abs(want_t).max(), pscale/float(min(g.dx, g.dy))), (shape, nm)
-            # mhh_pres_exec takes this form by itself: same bits as the three stages
+            # mhh_pres_exec in this form (by itself only on large grids): same bits as the three stages
             d2 = B.DevCase(be, c); f2 = d2.fields()
-            B.ok(be, be.lib.mhh_pres_exec(plan, d2.G, C.byref(f2), dt, be.stream))
+            os.environ["MHH_PRES_LDS"] = "1"
+            try:
+                B.ok(be, be.lib.mhh_pres_exec(plan, d2.G, C.byref(f2), dt, be.stream))
+            finally:
+                os.environ.pop("MHH_PRES_LDS", None)
             for x, y in ((d.p, d2.p), (d.ut, d2.ut), (d.vt, d2.vt), (d.wt, d2.wt)):
                 assert same(be.host(x), be.host(y))
             # and it is a projection: nothing left for a second solve
