@@ -883,6 +883,9 @@ static int pres_exec_fused(mhh_pres_plan* P, const mhh_grid* g, const mhh_fields
 #define MHH_PRES_LDS_BT 1024       // largest block (= itot) of the x-stage kernels: bounds their registers
 #endif
 static constexpr int LDS_RG = MHH_PRES_LDS_RG, LDS_BT = MHH_PRES_LDS_BT;
+// the transform sizes compiled with constant strides (the benchmark grids): itot = 512 in double, itot = 1024 in single precision;
+// jtot = 512 (at 1024 the unrolled passes no longer fit the 128 registers of a 1024-thread block). Everything else runs the same kernels with the sizes as run-time values.
+template<class TF> static constexpr int lds_nx_ct() { return sizeof(TF) == 8 ? 8 : 9; }
 static int ilog2(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
 static size_t lds_bytes_x(const mhh_pres_plan* P, int rows) { return ((size_t)rows*(lds_fft::lpad(P->itot/2) + 2) + P->itot) * 2*P->esz; }
 static size_t lds_bytes_y(const mhh_pres_plan* P)           { return ((size_t)8*lds_fft::lpad(P->jtot) + P->jtot) * 2*P->esz; }
@@ -910,10 +913,13 @@ static int pres_lds_setup_t(mhh_pres_plan* P)
     hipLaunchKernelGGL(lds_fft::pres_lds_factor_kernel<TF>, dim3((P->jtot + 63)/64, P->itot/2 + 1), dim3(64), 0, 0, static_cast<TF*>(P->w3l), lds_solve_args<TF>(P));
     MHH_LAUNCH_CHECK();
     MHH_HIP_TRY(hipStreamSynchronize(0));
-    MHH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_fft::pres_in_fftx_kernel<TF, LDS_RG, LDS_BT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_x(P, 8)));
-    MHH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_fft::pres_ysolve_kernel<TF, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_y(P)));
-    MHH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_fft::pres_ysolve_kernel<TF, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_y(P)));
-    MHH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_fft::pres_ifftx_out_kernel<TF, LDS_RG, LDS_BT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_x(P, 9)));
+    const int bx8 = (int)lds_bytes_x(P, 8), bx9 = (int)lds_bytes_x(P, 9), by = (int)lds_bytes_y(P);
+#define LDS_ATTR(kernel, bytes) MHH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes))
+    LDS_ATTR((lds_fft::pres_in_fftx_kernel<TF, LDS_RG, LDS_BT, 0>), bx8);   LDS_ATTR((lds_fft::pres_in_fftx_kernel<TF, LDS_RG, LDS_BT, lds_nx_ct<TF>()>), bx8);
+    LDS_ATTR((lds_fft::pres_ifftx_out_kernel<TF, LDS_RG, LDS_BT, 0>), bx9); LDS_ATTR((lds_fft::pres_ifftx_out_kernel<TF, LDS_RG, LDS_BT, lds_nx_ct<TF>()>), bx9);
+    LDS_ATTR((lds_fft::pres_ysolve_kernel<TF, 512, 0>), by); LDS_ATTR((lds_fft::pres_ysolve_kernel<TF, 1024, 0>), by);
+    LDS_ATTR((lds_fft::pres_ysolve_kernel<TF, 512, 9>), by);
+#undef LDS_ATTR
     return MHH_OK;
 }
 static int pres_lds_setup(mhh_pres_plan* P, const mhh_grid* g)
@@ -951,14 +957,17 @@ MHH_API int mhh_pres_lds_stage(mhh_pres_plan* P, const mhh_grid* g, const mhh_fi
         if (int e = pres_input_halos(g, 2, f, stream)) return e;
 #define CALL(TF) [&]{ lds_fft::PresLdsIn<TF> a{make_grid<TF>(g), cp<TF>(f->u), cp<TF>(f->v), cp<TF>(f->w), cp<TF>(f->ut), cp<TF>(f->vt), cp<TF>(f->wt), \
                           cp<TF>(f->rhoref), cp<TF>(f->rhorefh), TF(1.)/TF(dt), static_cast<C2<TF>*>(P->spec), static_cast<const C2<TF>*>(P->tx), ilog2(P->itot/2), kc}; \
-                      hipLaunchKernelGGL((lds_fft::pres_in_fftx_kernel<TF, LDS_RG, LDS_BT>), xgrid, dim3(P->itot), lds_bytes_x(P, 8), st, a); return MHH_OK; }()
+                      if (a.nx == lds_nx_ct<TF>()) hipLaunchKernelGGL((lds_fft::pres_in_fftx_kernel<TF, LDS_RG, LDS_BT, lds_nx_ct<TF>()>), xgrid, dim3(P->itot), lds_bytes_x(P, 8), st, a); \
+                      else hipLaunchKernelGGL((lds_fft::pres_in_fftx_kernel<TF, LDS_RG, LDS_BT, 0>), xgrid, dim3(P->itot), lds_bytes_x(P, 8), st, a); return MHH_OK; }()
         if (int e = MHH_DISPATCH(g, CALL)) return e;
 #undef CALL
     }
     else if (stage == 2)
     {
-#define CALL(TF) [&]{ if (P->jtot <= 512) hipLaunchKernelGGL((lds_fft::pres_ysolve_kernel<TF, 512>), dim3(P->itot/2), dim3(P->jtot), lds_bytes_y(P), st, lds_solve_args<TF>(P)); \
-                      else                hipLaunchKernelGGL((lds_fft::pres_ysolve_kernel<TF, 1024>), dim3(P->itot/2), dim3(P->jtot), lds_bytes_y(P), st, lds_solve_args<TF>(P)); return MHH_OK; }()
+#define CALL(TF) [&]{ const dim3 yg(P->itot/2), yb(P->jtot); const size_t yl = lds_bytes_y(P); const auto ya = lds_solve_args<TF>(P); \
+                      if (P->jtot == 512)       hipLaunchKernelGGL((lds_fft::pres_ysolve_kernel<TF, 512, 9>), yg, yb, yl, st, ya); \
+                      else if (P->jtot < 512)   hipLaunchKernelGGL((lds_fft::pres_ysolve_kernel<TF, 512, 0>), yg, yb, yl, st, ya); \
+                      else                      hipLaunchKernelGGL((lds_fft::pres_ysolve_kernel<TF, 1024, 0>), yg, yb, yl, st, ya); return MHH_OK; }()
         if (int e = MHH_DISPATCH(g, CALL)) return e;
 #undef CALL
     }
@@ -967,7 +976,8 @@ MHH_API int mhh_pres_lds_stage(mhh_pres_plan* P, const mhh_grid* g, const mhh_fi
         MHH_REQUIRE(f && f->p && f->ut && f->vt && f->wt, "null field");
 #define CALL(TF) [&]{ lds_fft::PresLdsOut<TF> a{make_grid<TF>(g), static_cast<const C2<TF>*>(P->spec), static_cast<const C2<TF>*>(P->tx), \
                           mp<TF>(f->p), mp<TF>(f->ut), mp<TF>(f->vt), mp<TF>(f->wt), ilog2(P->itot/2), kc}; \
-                      hipLaunchKernelGGL((lds_fft::pres_ifftx_out_kernel<TF, LDS_RG, LDS_BT>), xgrid, dim3(P->itot), lds_bytes_x(P, 9), st, a); return MHH_OK; }()
+                      if (a.nx == lds_nx_ct<TF>()) hipLaunchKernelGGL((lds_fft::pres_ifftx_out_kernel<TF, LDS_RG, LDS_BT, lds_nx_ct<TF>()>), xgrid, dim3(P->itot), lds_bytes_x(P, 9), st, a); \
+                      else hipLaunchKernelGGL((lds_fft::pres_ifftx_out_kernel<TF, LDS_RG, LDS_BT, 0>), xgrid, dim3(P->itot), lds_bytes_x(P, 9), st, a); return MHH_OK; }()
         if (int e = MHH_DISPATCH(g, CALL)) return e;
 #undef CALL
     }

@@ -135,6 +135,62 @@ template<int S, bool WL, class TF> __device__ __forceinline__ void fft_batch(C2<
     }
 }
 
+// The same with the size known at compile time (NLOG > 0; NLOG == 0 forwards to the run-time form): the passes unroll, radices
+// and strides are constants and the LDS addresses of a pass one base plus immediates. TWC: the twiddles of a thread are the same
+// in every call, so a kernel that transforms in a loop keeps them in registers (fft_twiddles_ct fills tw once).
+constexpr int fft_np(int nlog) { return nlog ? (nlog + 2)/3 : 1; }      // passes (array extent of the register-held twiddles)
+template<int NLOG> struct FftCT
+{
+    static constexpr int first = (NLOG % 3) ? (NLOG % 3) : 3, npass = (NLOG + 2) / 3;
+    static constexpr int lr(int p) { return p ? 3 : first; }
+    static constexpr int ls(int p) { return p ? first + 3*(p-1) : 0; }
+};
+template<int NLOG, class TF> __device__ __forceinline__ void fft_twiddles_ct(const C2<TF>* T, int tshift, int l, C2<TF> (&tw)[fft_np(NLOG)][7])
+{
+    typedef FftCT<NLOG> F;
+#pragma unroll
+    for (int p=1; p<F::npass; ++p)
+    {
+        const int k = l & ((1 << F::ls(p)) - 1), q = NLOG - F::ls(p) - 3 + tshift;
+#pragma unroll
+        for (int r=1; r<8; ++r) tw[p][r-1] = T[(r*k) << q];
+    }
+}
+template<int S, bool WL, int NLOG, bool TWC, class TF>
+__device__ __forceinline__ void fft_batch_ct(C2<TF>* D, const C2<TF>* T, int tshift, int l, int n, bool active, const C2<TF> (&tw)[fft_np(NLOG)][7])
+{
+    if constexpr (NLOG == 0) fft_batch<S, WL>(D, T, tshift, l, n, active);
+    else
+    {
+        typedef FftCT<NLOG> F;
+        C2<TF> v[8];
+#pragma unroll
+        for (int p=0; p<F::npass; ++p)
+        {
+            if (active) fft_gather(D, l, NLOG, v);
+            fft_sync<WL>();
+            if (active)
+            {
+                if constexpr (TWC)
+                {
+                    if (p > 0)          // radix 8 with this thread's own twiddles
+                    {
+#pragma unroll
+                        for (int r=1; r<8; ++r) v[r] = mul_tw<S>(v[r], tw[p][r-1]);
+                        dft8<S>(v);
+                        const int k = l & ((1 << F::ls(p)) - 1), o = ((l - k) << 3) + k;
+#pragma unroll
+                        for (int r=0; r<8; ++r) D[lpad(o + (r << F::ls(p)))] = v[r];
+                    }
+                    else fft_scatter<S>(D, T, tshift, l, NLOG, F::lr(0), 0, v);
+                }
+                else fft_scatter<S>(D, T, tshift, l, NLOG, F::lr(p), F::ls(p), v);
+            }
+            fft_sync<WL>();
+        }
+    }
+}
+
 // ======================================================================================================================
 // (1) Pres_2::input + the transform along x. Block = 8 rows j0..j0+7, marching up through KC levels; thread = column i.
 // ======================================================================================================================
@@ -148,7 +204,7 @@ struct PresLdsIn
     int nx;                           // log2(itot/2)
     int kc;                           // levels per block
 };
-template<class TF, int RG, int BT>
+template<class TF, int RG, int BT, int NX>
 __global__ void __launch_bounds__(BT) pres_in_fftx_kernel(const PresLdsIn<TF> a)
 {
     HIP_DYNAMIC_SHARED(double, lds_raw);
@@ -202,7 +258,7 @@ __global__ void __launch_bounds__(BT) pres_in_fftx_kernel(const PresLdsIn<TF> a)
             sched_fence();
         }
         __syncthreads();
-        fft_batch<-1, true>(D + (active ? slot : 0)*rp, T, 1, l, a.nx, active);
+        { const C2<TF> none[fft_np(NX)][7] = {}; fft_batch_ct<-1, true, NX, false>(D + (active ? slot : 0)*rp, T, 1, l, a.nx, active, none); }
         __syncthreads();
         // real-to-complex: X[kx] = E + exp(-2 pi i kx / itot) O from Z[kx] and Z[nh - kx]; one (kx, row) element per thread and turn,
         // rows fastest: eight neighbouring threads write one 128-byte (fp64) piece of S[k][kx][j0..j0+7]
@@ -276,7 +332,7 @@ __global__ void __launch_bounds__(64) pres_lds_factor_kernel(TF* __restrict__ W3
         inv = recip(tdma_diag_lds(a, bm, mean, k) - a.a[k]*w3);
     }
 }
-template<class TF, int BT>
+template<class TF, int BT, int NY>
 __global__ void __launch_bounds__(BT) pres_ysolve_kernel(const PresLdsSolve<TF> a)
 {
     HIP_DYNAMIC_SHARED(double, lds_raw);
@@ -286,6 +342,9 @@ __global__ void __launch_bounds__(BT) pres_ysolve_kernel(const PresLdsSolve<TF> 
     const int ky = threadIdx.x, kx = blockIdx.x;   // blockDim.x == jtot
     T[ky] = a.Ty[ky];
     const int team = N >> 3, slot = ky / team, l = ky - slot*team;        // slot < 8 always
+    constexpr bool TWC = (NY > 0 && BT <= 512);                           // twiddles in registers where the register file has the room
+    C2<TF> tw[fft_np(NY)][7];
+    if constexpr (TWC) { __syncthreads(); fft_twiddles_ct<NY>(T, 0, l, tw); }
     const size_t lev = (size_t)a.ncol*N, wlev = (size_t)(a.ncol + 1)*N;
     C2<TF>* Sc = a.S + (size_t)kx*N + ky;
     const TF* Wc = a.W3 + (size_t)kx*N + ky;
@@ -315,7 +374,7 @@ __global__ void __launch_bounds__(BT) pres_ysolve_kernel(const PresLdsSolve<TF> 
             for (int m=0; m<8; ++m) if (k0 + 8 + m < kmax) q[m] = Sc[(size_t)(k0 + 8 + m)*lev];
         }
         __syncthreads();
-        fft_batch<-1, (BT <= 512)>(D + slot*rp, T, 0, l, a.ny, true);
+        fft_batch_ct<-1, (BT <= 512), NY, TWC>(D + slot*rp, T, 0, l, a.ny, true, tw);
         if (BT <= 512) __syncthreads();
         C2<TF> r8[8];
 #pragma unroll
@@ -415,7 +474,7 @@ __global__ void __launch_bounds__(BT) pres_ysolve_kernel(const PresLdsSolve<TF> 
             for (int m=0; m<8; ++m) D[m*rp + lpad(ky)] = z[m];
             __syncthreads();
         }
-        fft_batch<+1, (BT <= 512)>(D + slot*rp, T, 0, l, a.ny, true);
+        fft_batch_ct<+1, (BT <= 512), NY, TWC>(D + slot*rp, T, 0, l, a.ny, true, tw);
         if (BT <= 512) __syncthreads();
 #pragma unroll
         for (int m=0; m<8; ++m) if (k0 + m < kmax) Sc[(size_t)(k0 + m)*lev] = D[m*rp + lpad(ky)];
@@ -435,7 +494,7 @@ struct PresLdsOut
     TF* p; TF* ut; TF* vt; TF* wt;
     int nx, kc;
 };
-template<class TF, int RG, int BT>
+template<class TF, int RG, int BT, int NX>
 __global__ void __launch_bounds__(BT) pres_ifftx_out_kernel(const PresLdsOut<TF> a)
 {
     HIP_DYNAMIC_SHARED(double, lds_raw);
@@ -488,7 +547,7 @@ __global__ void __launch_bounds__(BT) pres_ifftx_out_kernel(const PresLdsOut<TF>
             }
         }
         __syncthreads();
-        fft_batch<+1, true>(D + (active ? slot : 0)*rp, T, 1, l, a.nx, active);
+        { const C2<TF> none[fft_np(NX)][7] = {}; fft_batch_ct<+1, true, NX, false>(D + (active ? slot : 0)*rp, T, 1, l, a.nx, active, none); }
         __syncthreads();
         // rows of p: element i of row r at real index 2*lpad(i/2) + (i&1)
         const int oc = 2*lpad(tid >> 1) + (tid & 1), ow = 2*lpad(iw >> 1) + (iw & 1);
