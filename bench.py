@@ -237,10 +237,12 @@ def main():
             ev[1].record()
         if not rhs_only:
             hp.pres()
+            if ev is not None:
+                ev[3].record()
 
     for _ in range(args.warmup):
         one_step()
-    events = [tuple(Ev() for _ in range(3)) for _ in range(args.steps)]
+    events = [tuple(Ev() for _ in range(4)) for _ in range(args.steps)]
 
     def barrier():
         if on_gpu:
@@ -263,8 +265,8 @@ def main():
         elapsed = float(tt.item())
     ms = 1e3 * elapsed / args.steps
     cells = itot * jtot * ktot
-    rhs_ms = float(np.mean([a.elapsed_time(b) for a, b, _ in events]))   # fused RHS kernel, this rank, ms per launch
-    visc_ms = float(np.mean([c.elapsed_time(a) for a, _, c in events]))  # exec_viscosity (+ its cyclic fill), ms per call
+    rhs_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))   # fused RHS kernel, this rank, ms per launch
+    visc_ms = float(np.mean([e[2].elapsed_time(e[0]) for e in events]))  # exec_viscosity (+ its cyclic fill), ms per call
     local_cells = hp.grid.imax * hp.grid.jmax * hp.grid.kmax
     if overlapped:                       # the timed launch covers the interior rows only
         local_cells_rhs = hp.grid.imax * hp.rhs_rows_timed * hp.grid.kmax
@@ -287,6 +289,9 @@ def main():
         "alg_bytes_per_cell_full_step": hp.alg_bytes_rhs() + hp.alg_bytes_visc() + (0 if rhs_only else hp.alg_bytes_pres()),
         "hbm_frac_full_step": (hp.alg_bytes_rhs() + hp.alg_bytes_visc() + (0 if rhs_only else hp.alg_bytes_pres())) * local_cells / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
     }
+    if not rhs_only and not overlapped and not hp.slab:
+        out["pressure"] = {"ms": float(np.mean([e[1].elapsed_time(e[3]) for e in events])),
+                           "form": "transforms in LDS, 3 kernels (csrc/pres_lds.h)" if hp.lib.mhh_pres_exec_form(hp.plan) == 1 else "staged, rocFFT (csrc/k_pres.hip)"}
     out["build"] = args.build if not os.environ.get("MHH_LIB") or args.build == "fma" else os.path.basename(os.environ["MHH_LIB"])
     if world == 1 and not args.unfused and out["build"] == "default":
         out["roofline"]["traffic"], src = recorded_traffic(args.workload)      # FETCH_SIZE x 2 + WRITE_SIZE per launch, or null

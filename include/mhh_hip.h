@@ -272,6 +272,7 @@ int mhh_pres_exec(mhh_pres_plan* plan, const mhh_grid* g, const mhh_fields* f, d
  * Thomas sweeps (src/pres_2.cxx:202-263), 3 = transform back along x + p with ghost cells + Pres_2::output (:333-387).      */
 int   mhh_pres_lds_stage(mhh_pres_plan* plan, const mhh_grid* g, const mhh_fields* f, double dt, int stage, void* stream);
 int   mhh_pres_plan_has_lds_form(const mhh_pres_plan* plan);
+int   mhh_pres_exec_form(const mhh_pres_plan* plan);   /* what mhh_pres_exec will run: 0 = staged (rocFFT), 1 = transforms in LDS */
 void* mhh_pres_plan_spectral(mhh_pres_plan* plan);   /* device array between the stages: S[k][kx][j], complex */
 /* stages, exposed for the slab-decomposed driver and for parity tests */
 int mhh_pres_input (mhh_pres_plan* plan, const mhh_grid* g, const mhh_fields* f, double dt, void* p_packed, void* stream); /* pres_2.cxx:156-196, pres_4.cxx:256-317 */

@@ -80,6 +80,7 @@ SIGNATURES = {
     "mhh_pres_exec": (ci, [PLAN, GP, FP, cd, vp]),
     "mhh_pres_lds_stage": (ci, [PLAN, GP, FP, cd, ci, vp]),
     "mhh_pres_plan_has_lds_form": (ci, [PLAN]),
+    "mhh_pres_exec_form": (ci, [PLAN]),
     "mhh_pres_plan_spectral": (vp, [PLAN]),
     "mhh_pres_input": (ci, [PLAN, GP, FP, cd, vp, vp]),
     "mhh_pres_solve": (ci, [PLAN, GP, FP, vp, vp]),

@@ -989,6 +989,14 @@ MHH_API int mhh_pres_plan_has_lds_form(const mhh_pres_plan* P) { return (P && P-
 // the spectral array between the stages (tests): S[k][kx][j], complex
 MHH_API void* mhh_pres_plan_spectral(mhh_pres_plan* P) { return P ? P->spec : nullptr; }
 
+// the form mhh_pres_exec takes for this plan: 0 = staged (rocFFT), 1 = transforms in LDS
+MHH_API int mhh_pres_exec_form(const mhh_pres_plan* P)
+{
+    if (!P || !P->lds_ok) return 0;
+    const char* le = getenv("MHH_PRES_LDS");
+    const bool lds_large = (long long)P->itot*P->jtot*P->ktot >= (1ll << 26) && P->itot >= 512;
+    return (le ? !strcmp(le, "1") : lds_large) ? 1 : 0;
+}
 MHH_API int mhh_pres_exec(mhh_pres_plan* P, const mhh_grid* g, const mhh_fields* f, double dt, void* stream)
 {
     MHH_REQUIRE(P != nullptr, "plan");
@@ -998,9 +1006,7 @@ MHH_API int mhh_pres_exec(mhh_pres_plan* P, const mhh_grid* g, const mhh_fields*
     // The LDS form pays where the arrays are far larger than the caches and there is a block per CU for the y stage (measured on
     // MI355X: 512^3 fp64 5.8 -> 5.0 ms, 1024 x 1024 x 256 fp32 7.9 -> 5.0 ms; 256^3 0.78 -> 0.92 ms, so not there).
     // MHH_PRES_LDS=0 / 1: never / wherever the plan has the form.
-    const char* le = getenv("MHH_PRES_LDS");
-    const bool lds_large = (long long)P->itot*P->jtot*P->ktot >= (1ll << 26) && P->itot >= 512;
-    if (P->lds_ok && (le ? !strcmp(le, "1") : lds_large))
+    if (mhh_pres_exec_form(P) == 1)
     {
         for (int stage=1; stage<=3; ++stage) if (int e = mhh_pres_lds_stage(P, g, f, dt, stage, stream)) return e;
         return MHH_OK;
