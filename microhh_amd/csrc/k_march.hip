@@ -129,6 +129,10 @@ rhs25_march_kernel(const GridDev<typename lane_of<VT>::scalar> g, const MarchFie
 {
     using TF = typename lane_of<VT>::scalar;
     constexpr int CW = lane_of<VT>::cells;
+    // CW = 2: a lane holds cells i and i + 64 of the wave's 128 (NOT neighbours: every LDS read of a plane is then two unit-stride
+    // words across the lanes, free of bank conflicts -- neighbouring pairs read at odd offsets are stride-2 words, two-way conflicts
+    // on 43 % of the LDS cycles of that form). SEC = distance to the lane's second cell; rows are whole tiles (imax % 128 == 0).
+    constexpr int SEC = (CW == 2) ? 64 : 0;
     static_assert(PB == 16 || PB == 4, "piece size of the LDS-DMA copies");
     constexpr int VEC = 16 / (int)sizeof(TF);                       // elements per 16-byte DMA piece
     constexpr int AL = (PB == 16) ? VEC : 1;                        // granularity of tile widths / origins in elements
@@ -151,20 +155,19 @@ rhs25_march_kernel(const GridDev<typename lane_of<VT>::scalar> g, const MarchFie
     const int i0 = g.istart + bx*64*CW, j0 = mt.jbase + by*NJ;
     const int kb = g.kstart + kcn*mt.kc;
     const int ke = (kb + mt.kc < g.kend) ? kb + mt.kc : g.kend;
-    const int i = i0 + tx*CW, j = j0 + ty;                          // the lane's (first) cell; CW = 2 needs imax even (the launcher checks)
-    const bool active = (i < g.iend) && (j < mt.jlim);
-    const int ci = (i < g.iend) ? i : g.iend-CW, cj = (j < mt.jlim) ? j : mt.jlim-1;   // clamped column for the window loads
+    const int i = i0 + tx, j = j0 + ty;                             // the lane's (first) cell; CW = 2 needs whole 128-cell tiles (the launcher checks)
+    const bool active = (i + SEC < g.iend) && (j < mt.jlim);
+    const int ci = (i + SEC < g.iend) ? i : g.iend-1-SEC, cj = (j < mt.jlim) ? j : mt.jlim-1;   // clamped column for the window loads
     const int col = ci + cj*jj;
     const int ij = col;
-    const int l = (ty+3)*TI + (tx*CW+3), le = (ty+1)*TE + (tx*CW+EX);
-    // a plane in LDS as seen from the lane's cell: [o] = the lane value o cells away (CW = 2: two neighbouring cells, read as two
-    // words -- the compiler assembles the unaligned pairs from aligned 8-byte reads with v_pk_mov_b32)
+    const int l = (ty+3)*TI + (tx+3), le = (ty+1)*TE + (tx+EX);
+    // a plane in LDS as seen from the lane's cell: [o] = the lane value o cells away (CW = 2: the lane's two cells, one ds_read2_b32)
     struct LV
     {
         const TF* p;
-        __device__ __forceinline__ VT operator[](int o) const { if constexpr (CW == 1) return p[o]; else return VT(p[o], p[o+1]); }
+        __device__ __forceinline__ VT operator[](int o) const { if constexpr (CW == 1) return p[o]; else return VT(p[o], p[o+SEC]); }
     };
-    auto ld2d = [&](const TF* q, int c) -> VT { if constexpr (CW == 1) return q[c]; else return VT(q[c], q[c+1]); };   // a 2-D surface array at the lane's column
+    auto ld2d = [&](const TF* q, int c) -> VT { if constexpr (CW == 1) return q[c]; else return VT(q[c], q[c+SEC]); };   // a 2-D surface array at the lane's column
 
     // interior level of an updating iteration: faces k and k+1 of the centred fields and the w "faces" k-1, k all 6th order
     int kf0 = (kb > g.kstart+3) ? kb : g.kstart+3;                 // first interior level of the chunk
@@ -265,16 +268,16 @@ rhs25_march_kernel(const GridDev<typename lane_of<VT>::scalar> g, const MarchFie
     // Tendencies are touched once per kernel: their loads and stores carry the non-temporal hint, so that they stream past L2
     // instead of evicting the field planes that neighbouring tiles re-read (512^3: HBM fetch 15.4 -> 14.1 GB per launch, same
     // time; -DMHH_MARCH_NO_NT for A/B runs)
-    auto gl = [](const TF* base, unsigned bo) -> VT { if constexpr (CW == 1) return gload(base, bo); else return VT(gload(base, bo), gload(base, bo + 4u)); };
+    auto gl = [](const TF* base, unsigned bo) -> VT { if constexpr (CW == 1) return gload(base, bo); else return VT(gload(base, bo), gload(base, bo + 4u*SEC)); };
 #if defined(MHH_EXP_NOTEND) || defined(MHH_EXP_NOMEM)   // diagnostic builds (fp64): no tendency traffic / the arithmetic alone (stores behind a condition that never holds)
     auto tld = [](const TF*, unsigned bo) -> VT { return VT(TF(bo)); };
     auto tst = [](TF* base, unsigned bo, VT v) { if constexpr (CW == 1) { if (v == TF(-1.2345e300)) gstore(base, bo, v); } };
 #elif !defined(MHH_MARCH_NO_NT)
-    auto tld = [](const TF* base, unsigned bo) -> VT { if constexpr (CW == 1) return gload_stream(base, bo); else return VT(gload_stream(base, bo), gload_stream(base, bo + 4u)); };
-    auto tst = [](TF* base, unsigned bo, VT v) { if constexpr (CW == 1) gstore_stream(base, bo, v); else { gstore_stream(base, bo, v.lo()); gstore_stream(base, bo + 4u, v.hi()); } };
+    auto tld = [](const TF* base, unsigned bo) -> VT { if constexpr (CW == 1) return gload_stream(base, bo); else return VT(gload_stream(base, bo), gload_stream(base, bo + 4u*SEC)); };
+    auto tst = [](TF* base, unsigned bo, VT v) { if constexpr (CW == 1) gstore_stream(base, bo, v); else { gstore_stream(base, bo, v.lo()); gstore_stream(base, bo + 4u*SEC, v.hi()); } };
 #else
-    auto tld = [](const TF* base, unsigned bo) -> VT { if constexpr (CW == 1) return gload(base, bo); else return VT(gload(base, bo), gload(base, bo + 4u)); };
-    auto tst = [](TF* base, unsigned bo, VT v) { if constexpr (CW == 1) gstore(base, bo, v); else { gstore(base, bo, v.lo()); gstore(base, bo + 4u, v.hi()); } };
+    auto tld = [](const TF* base, unsigned bo) -> VT { if constexpr (CW == 1) return gload(base, bo); else return VT(gload(base, bo), gload(base, bo + 4u*SEC)); };
+    auto tst = [](TF* base, unsigned bo, VT v) { if constexpr (CW == 1) gstore(base, bo, v); else { gstore(base, bo, v.lo()); gstore(base, bo + 4u*SEC, v.hi()); } };
 #endif
     unsigned bo0 = (unsigned)col * (unsigned)sizeof(TF);              // this column in a plane, one / two / three planes up
     unsigned bo1 = (unsigned)(col + kk) * (unsigned)sizeof(TF), bo2 = (unsigned)(col + 2*kk) * (unsigned)sizeof(TF);
@@ -653,11 +656,11 @@ int march_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* 
 }
 } // namespace
 
-// fp32: two cells per lane with packed arithmetic where the rows allow it (even imax); MHH_MARCH_F32X2=0 keeps one cell per lane
+// fp32: two cells per lane with packed arithmetic where the rows are whole 128-cell tiles; MHH_MARCH_F32X2=0 keeps one cell per lane
 static bool f32x2(const mhh_grid* g)
 {
     const char* e = getenv("MHH_MARCH_F32X2");
-    return g->imax % 2 == 0 && !(e && !strcmp(e, "0"));
+    return g->imax % 128 == 0 && !(e && !strcmp(e, "0"));
 }
 static int march_dispatch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, int j0, int j1, void* stream, int mode)
 {

@@ -567,7 +567,7 @@ def test_rhs_exec_other_scheme_pairs_run_as_two_calls(be, adv, dif):
 def test_fused_rhs_on_minimal_and_ragged_grids(be, dtype):
     """Smallest legal vertical extent (every level is wall-adjacent: no interior fast path), tiles narrower than a wave,
     a single row, and extents that are not multiples of the 64 x 4 tile: fused passes against the oracle's operator sequence."""
-    cases = [(cm.ADVEC_2I5, cm.DIFF_SMAG2, 1, [(8, 6, 6), (5, 3, 7), (66, 5, 9), (130, 3, 6)]),
+    cases = [(cm.ADVEC_2I5, cm.DIFF_SMAG2, 1, [(8, 6, 6), (5, 3, 7), (66, 5, 9), (130, 3, 6), (128, 5, 9), (256, 3, 6)]),   # rows of whole 128-cell tiles: two fp32 cells per lane
              (cm.ADVEC_4, cm.DIFF_4, 0, [(8, 6, 6), (6, 4, 5), (66, 5, 9)]),
              (cm.ADVEC_2, cm.DIFF_2, 0, [(4, 3, 2), (66, 5, 3)])]
     for adv, dif, sm, shapes in cases:
@@ -588,7 +588,7 @@ def test_advec25_and_diff_smag2_alone_marching_form_equals_per_field_kernels(be,
     """Advec::exec (2i5) and Diff::exec (smag2) as separate calls run the marching kernel with one operator's terms
     (u, v, w and the first unlimited scalar; further / flux-limited scalars per field): the bits of the per-field cell
     kernels after each of the two calls, on aligned, unaligned, ragged and minimal grids, with and without surface model."""
-    for shape, sm, lim in [((70, 10, 12), 1, (0, 0)), ((17, 9, 8), 0, (0, 1)), ((8, 6, 6), 1, (1, 0)), ((130, 3, 6), 1, (0, 0))]:
+    for shape, sm, lim in [((70, 10, 12), 1, (0, 0)), ((17, 9, 8), 0, (0, 1)), ((8, 6, 6), 1, (1, 0)), ((130, 3, 6), 1, (0, 0)), ((128, 5, 7), 1, (0, 0))]:
         g = cm.grid_2nd(*shape, gc=(3, 3, 2), dtype=dtype)
         c = cm.Case(g, nscalars=2)
         p = capi.MhhDiffParams(); p.cs = 0.23; p.tPr = 1./3.; p.surface_model = sm
@@ -690,7 +690,7 @@ def test_rhs25_march_tall_columns(be, dtype, rho):
     scalar, ragged in i and j: the fused pass equals the oracle's operator-by-operator result bit for bit."""
     adv, dif = cm.ADVEC_2I5, cm.DIFF_SMAG2
     O = cm.oracle()
-    for shape, ns in [((20, 6, 150), 1), ((66, 5, 31), 0), ((12, 9, 133), 1)]:
+    for shape, ns in [((20, 6, 150), 1), ((66, 5, 31), 0), ((12, 9, 133), 1), ((128, 6, 40), 1)]:
         g = cm.grid_2nd(*shape, gc=(3, 3, 1), dtype=dtype)
         c = cm.Case(g, nscalars=ns, rho=rho)
         p = capi.MhhDiffParams(); p.cs = 0.23; p.tPr = 1./3.; p.surface_model = 1
