@@ -14,7 +14,7 @@ bad = 0
 for it in range(n):
     dtype = np.float64 if rng.random() < 0.6 else np.float32
     pair = rng.integers(0, 2)
-    itot = int(rng.choice([4, 7, 16, 33, 64, 65, 70, 96, 130, 140])); jtot = int(rng.choice([1, 3, 4, 5, 9, 12, 17])); ktot = int(rng.integers(6, 40))
+    itot = int(rng.choice([4, 7, 16, 33, 64, 65, 70, 96, 128, 130, 140, 256])); jtot = int(rng.choice([1, 3, 4, 5, 9, 12, 17])); ktot = int(rng.integers(6, 40))
     if pair == 0:
         adv, dif, sm = cm.ADVEC_2I5, cm.DIFF_SMAG2, int(rng.integers(0, 2))
         if jtot < 3: jtot = 3

@@ -1,6 +1,7 @@
 """Randomised run of Pres::exec on the GPU against the CPU oracle (input -> spectral solve -> output) on random grid shapes,
 pres_2 and pres_4, both precisions: p and the corrected tendencies within the stated tolerance (1e-11 / 2e-4 of max|p|).
-Test infrastructure (imports tests/ and oracle/)."""
+A third argument "lds" draws power-of-two pres_2 grids and forces the form with the transforms in LDS (csrc/pres_lds.h) with a random
+number of levels per block; p is then compared with all its ghost cells. Test infrastructure (imports tests/ and oracle/)."""
 import os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -11,12 +12,16 @@ from microhh_amd import capi
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
+lds = len(sys.argv) > 3 and sys.argv[3] == "lds"
 be = B.get("hip"); O = cm.oracle()
 bad = 0; worst = 0.0
 for it in range(n):
     dtype = np.float64 if rng.random() < 0.6 else np.float32
     order = 2 if rng.random() < 0.6 else 4
     itot = int(rng.choice([4, 6, 8, 12, 16, 20, 30, 32, 48, 64])); jtot = int(rng.choice([1, 3, 4, 6, 8, 10, 16, 24])); ktot = int(rng.integers(4, 24))
+    if lds:
+        order = 2; itot = int(rng.choice([16, 32, 64, 128, 256, 512])); jtot = int(rng.choice([8, 16, 32, 64, 128, 256])); ktot = int(rng.integers(2, 40))
+        os.environ["MHH_PRES_LDS"] = "1"; os.environ["MHH_PRES_LDS_KC"] = str(int(rng.integers(1, 12)))
     if order == 2:
         g = cm.grid_2nd(itot, jtot, ktot, gc=(int(rng.integers(1, 4)), int(rng.integers(1, 4)), 1), dtype=dtype)
         c = cm.Case(g, rho="random", periodic=True)
@@ -39,9 +44,13 @@ for it in range(n):
     B.ok(be, be.lib.mhh_pres_plan_create(Gh, order, ptr(g.dz), ptr(g.dzhi), ptr(g.dzi4), ptr(g.dzhi4), ptr(c.rhoref), ptr(c.rhorefh), C.byref(plan)))
     B.ok(be, be.lib.mhh_pres_exec(plan, d.G, C.byref(f), dt, be.stream))
     sl = (slice(g.kstart, g.kend), slice(g.jstart, g.jend), slice(g.istart, g.iend))
+    if lds:
+        assert be.lib.mhh_pres_exec_form(plan) == 1
+        sl = (slice(g.kstart-1, g.kend), slice(None), slice(None))          # p with its periodic halo and the ghost level below
     tol = 1e-11 if dtype == np.float64 else 2e-4
     scale = np.abs(p_want[sl]).max()
     err = np.abs(be.host(d.p)[sl] - p_want[sl]).max() / scale
+    sl = (slice(g.kstart, g.kend), slice(g.jstart, g.jend), slice(g.istart, g.iend))
     gscale = max(np.abs(ut[sl] - c.ut[sl]).max(), np.abs(vt[sl] - c.vt[sl]).max(), np.abs(wt[sl] - c.wt[sl]).max())
     terr = max(np.abs(be.host(x)[sl] - w_[sl]).max() for x, w_ in ((d.ut, ut), (d.vt, vt), (d.wt, wt))) / gscale
     be.lib.mhh_pres_plan_destroy(plan)
