@@ -51,7 +51,8 @@ struct mhh_pres_plan
 };
 
 
-template<class TF> struct C2 { TF x, y; };
+// naturally aligned (16 bytes in fp64): one ds_read_b128 / global_load_dwordx4 per number instead of two 8-byte halves
+template<class TF> struct alignas(2*sizeof(TF)) C2 { TF x, y; };
 #include "pres_lds.h"
 
 // ---- host-side coefficient tables (Pres_2::set_values src/pres_2.cxx:125-153; Pres_4::set_values src/pres_4.cxx:179-252)
@@ -887,8 +888,8 @@ static constexpr int LDS_RG = MHH_PRES_LDS_RG, LDS_BT = MHH_PRES_LDS_BT;
 // jtot = 512 (at 1024 the unrolled passes no longer fit the 128 registers of a 1024-thread block). Everything else runs the same kernels with the sizes as run-time values.
 template<class TF> static constexpr int lds_nx_ct() { return sizeof(TF) == 8 ? 8 : 9; }
 static int ilog2(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
-static size_t lds_bytes_x(const mhh_pres_plan* P, int rows) { return ((size_t)rows*(lds_fft::lpad(P->itot/2) + 2) + P->itot) * 2*P->esz; }
-static size_t lds_bytes_y(const mhh_pres_plan* P)           { return ((size_t)8*lds_fft::lpad(P->jtot) + P->jtot) * 2*P->esz; }
+static size_t lds_bytes_x(const mhh_pres_plan* P, int rows) { return ((size_t)rows*(P->itot/2 + 2) + P->itot) * 2*P->esz; }
+static size_t lds_bytes_y(const mhh_pres_plan* P)           { return ((size_t)8*P->jtot + P->jtot) * 2*P->esz; }
 template<class TF>
 static lds_fft::PresLdsSolve<TF> lds_solve_args(const mhh_pres_plan* P)
 {

@@ -15,7 +15,7 @@ import csv, glob, sys, collections
 out=sys.argv[1]
 agg=collections.defaultdict(lambda: collections.defaultdict(list))
 def short(k):
-    for key,name in (("visc_march","viscmarch"),("rhs44_march","march4"),("rhs25_march","march"),("Rhs25","Rhs25cell"),("Viscosity","Visc"),("tdma","tdma"),("PresIn","PresIn"),("PresOut","PresOut"),("unpack","unpack"),("Rhs44","Rhs44"),("Rhs22","Rhs22"),("hdma","hdma")):
+    for key,name in (("pres_in_fftx","pres_lds_in"),("pres_ysolve","pres_lds_ysolve"),("pres_ifftx_out","pres_lds_out"),("visc_march","viscmarch"),("rhs44_march","march4"),("rhs25_march","march"),("Rhs25","Rhs25cell"),("Viscosity","Visc"),("tdma","tdma"),("PresIn","PresIn"),("PresOut","PresOut"),("unpack","unpack"),("Rhs44","Rhs44"),("Rhs22","Rhs22"),("hdma","hdma")):
         if key in k: return name
     return None
 for f in glob.glob(out+"/pmc*/**/*counter_collection.csv", recursive=True):
