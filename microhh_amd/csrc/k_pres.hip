@@ -950,7 +950,7 @@ MHH_API int mhh_pres_lds_stage(mhh_pres_plan* P, const mhh_grid* g, const mhh_fi
     MHH_REQUIRE(stage >= 1 && stage <= 3, "stage");
     hipStream_t st = as_stream(stream);
     const int kc = lds_levels_per_block(P);
-    const dim3 xgrid(P->jtot/8, (P->ktot + kc-1)/kc);
+    const dim3 xgrid((unsigned)(P->jtot/8) * (unsigned)((P->ktot + kc-1)/kc));        // strips x chunks, decoded by lds_strip_of_block
     if (stage == 1)
     {
         MHH_REQUIRE(f && f->u && f->v && f->w && f->ut && f->vt && f->wt && f->rhoref && f->rhorefh, "null field");

@@ -202,6 +202,16 @@ __device__ __forceinline__ void fft_batch_ct(C2<TF>* D, const C2<TF>* T, int tsh
     }
 }
 
+// Blocks of the x-stage kernels: a strip of 8 rows x a chunk of kc levels, launched as ONE dimension so that the strips an XCD
+// works on are neighbours (block id % 8 = XCD): the row a strip shares with the next one (v, vt at j0+8; the spectral row j0-1)
+// is then fetched into ONE L2 instead of two.
+__device__ __forceinline__ void lds_strip_of_block(int nstrips, int& strip, int& chunk)
+{
+    const unsigned id = blockIdx.x;
+    if ((nstrips & 7) == 0) { const unsigned x = id & 7u, t = id >> 3, per = (unsigned)nstrips >> 3; chunk = (int)(t / per); strip = (int)(x*per + (t - (unsigned)chunk*per)); }
+    else { chunk = (int)(id / (unsigned)nstrips); strip = (int)(id - (unsigned)chunk*(unsigned)nstrips); }
+}
+
 // ======================================================================================================================
 // (1) Pres_2::input + the transform along x. Block = 8 rows j0..j0+7, marching up through KC levels; thread = column i.
 // ======================================================================================================================
@@ -225,7 +235,8 @@ __global__ void __launch_bounds__(BT) pres_in_fftx_kernel(const PresLdsIn<TF> a)
     C2<TF>* T = D + 8*rp;
     const int tid = threadIdx.x;                   // blockDim.x == itot
     T[tid] = a.Tx[tid];
-    const int j0 = blockIdx.x*8, k0 = blockIdx.y*a.kc, k1 = (k0 + a.kc < g.kmax) ? k0 + a.kc : g.kmax;
+    int strip, chunk; lds_strip_of_block(jtot >> 3, strip, chunk);
+    const int j0 = strip*8, k0 = chunk*a.kc, k1 = (k0 + a.kc < g.kmax) ? k0 + a.kc : g.kmax;
     const int jj = g.icells, kk = g.ijcells;
     const int c0 = (tid + g.igc) + (j0 + g.jgc)*jj;
     const int team = nh >> 3, slot = tid / team, l = tid - slot*team;     // the transform this thread works on in the passes
@@ -515,7 +526,8 @@ __global__ void __launch_bounds__(BT) pres_ifftx_out_kernel(const PresLdsOut<TF>
     C2<TF>* T = D + 9*rp;
     const int tid = threadIdx.x;                   // blockDim.x == itot
     T[tid] = a.Tx[tid];
-    const int j0 = blockIdx.x*8, k0 = blockIdx.y*a.kc, k1 = (k0 + a.kc < g.kmax) ? k0 + a.kc : g.kmax;
+    int strip, chunk; lds_strip_of_block(jtot >> 3, strip, chunk);
+    const int j0 = strip*8, k0 = chunk*a.kc, k1 = (k0 + a.kc < g.kmax) ? k0 + a.kc : g.kmax;
     const int jj = g.icells, kk = g.ijcells;
     const int team = nh >> 3, slot = tid / team, l = tid - slot*team;
     const bool active = slot < 9;
