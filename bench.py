@@ -161,6 +161,8 @@ def main():
     ap.add_argument("--build", default="default", choices=["default", "fma"],
                     help="fma = the second, named build (microhh_amd/libmhh_hip_fma.so: marching kernels with FMA contraction; "
                          "tolerance stated in tests/test_fma_build.py) instead of the bit-exact default")
+    ap.add_argument("--graph", action="store_true", help="N=1 on a GPU: the timed steps replay one hipGraph of a step (HotPath.capture_step); "
+                    "the per-kernel event times then come from untimed call-by-call steps before them")
     ap.add_argument("--no-fma-line", action="store_true", help="skip the extra timing of the named FMA build (fma_build in the JSON line)")
     ap.add_argument("--force-slab", action="store_true", help="N=1 only: run the slab code path (halo pack/unpack, split pressure solve) with local copies as exchanges")
     args = ap.parse_args()
@@ -254,9 +256,18 @@ def main():
     barrier()
     if on_gpu and (world > 1 or os.environ.get("MHH_FORCE_COMM") == "1") and not args.share_gpu:
         hp.comm_timing = []                  # device-event pairs around every exchange of the timed steps
+    use_graph = args.graph and on_gpu and world == 1 and not hp.slab and not args.unfused
+    if use_graph:
+        for n in range(args.steps):          # event times of the kernels: call-by-call steps, outside the timed region
+            one_step(events[n])
+        graph = hp.capture_step()
+        barrier()
     t0 = time.perf_counter()
     for n in range(args.steps):
-        one_step(events[n])
+        if use_graph:
+            graph.replay()
+        else:
+            one_step(events[n])
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -279,7 +290,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32" if rhs_only else "f64", "data": "synthetic",
         "config": {"workload": desc, "grid": [itot, jtot, ktot], "decomposition": "slab-y npx=1 npy=%d" % world,
-                   "rhs": "unfused" if args.unfused else "fused", "halo_overlap": bool(overlapped)},
+                   "rhs": "unfused" if args.unfused else "fused", "halo_overlap": bool(overlapped), "launch": "hipGraph replay" if use_graph else "call by call"},
         "roofline": {"bound": "hbm", "kernel": "fused RHS (advec+diff) pass" if not args.unfused else "advec+diff launches",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None, "alg_bytes_per_cell": hp.alg_bytes_rhs(), "ms_per_launch": rhs_ms},

@@ -95,7 +95,7 @@ MHH_API unsigned long long mhh_halo_buffer_elems(const mhh_grid* g, int nf)
 //   xbuf  [q][k][jl][kxl]        all-to-all buffer, q = destination / source rank, kx = q*nxb + kxl (zero padded)
 //   specy [k][kxl][j]            after the exchange, j over the full jtot, unit stride for the y transform
 // =======================================================================================================
-template<class TF> struct C2 { TF x, y; };
+template<class TF> struct alignas(2*sizeof(TF)) C2 { TF x, y; };   // naturally aligned: one 16-byte access per fp64 number
 
 struct mhh_pres_slab_plan
 {

@@ -493,6 +493,19 @@ class HotPath:
             self.rhs()
         self.pres()
 
+    def capture_step(self):
+        """One step recorded as a hipGraph (single GPU): every entry point of the library only enqueues work on the stream it is
+        given -- no allocation, no synchronisation, no host round trip inside a step -- so the dozen launches of a step (cyclic
+        fills, exec_viscosity, fused RHS, the pressure kernels or rocFFT's) replay as ONE graph launch. Matters where a step is
+        short (256^3: 1.6 ms, 64^3: 0.1 ms); returns the graph, `graph.replay()` runs a step on the same fields."""
+        assert self.on_gpu and not self.slab, "graph capture: single-GPU path"
+        torch = self.torch
+        self.step(); self.sync()                       # everything created lazily (rocFFT work areas) exists before the capture
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self.step()
+        return graph
+
     # -- reductions (local max, then MAX over ranks: Master::max, src/master_parallel.cxx:233-266) --------------
     def _allmax(self, v):
         if self.npy == 1 and not self._force_comm:
