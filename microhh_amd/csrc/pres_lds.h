@@ -26,17 +26,6 @@ struct alignas(16) LdsUnit { double x, y; };           // the dynamic LDS block 
 template<class TF> __device__ __forceinline__ C2<TF> operator+(C2<TF> a, C2<TF> b) { return C2<TF>{a.x + b.x, a.y + b.y}; }
 template<class TF> __device__ __forceinline__ C2<TF> operator-(C2<TF> a, C2<TF> b) { return C2<TF>{a.x - b.x, a.y - b.y}; }
 
-// a complex number through uniform base + 32-bit byte offset (gload, gfx950_prims.h), as one 8- / 16-byte access
-template<class TF> __device__ __forceinline__ C2<TF> gload_c2(const C2<TF>* base, unsigned off)
-{
-#if defined(__clang__)
-    typedef TF pair_t __attribute__((ext_vector_type(2)));
-    const pair_t t = gload(reinterpret_cast<const pair_t*>(base), off);
-    return C2<TF>{t.x, t.y};
-#else
-    return gload(base, off);
-#endif
-}
 // Where element i of a transform sits in LDS: the low bits of the index are XOR-ed with the bits above them, so that BOTH access
 // patterns of a pass are free of bank conflicts (MI355X_MICROARCH.md, LDS): consecutive elements read with ds_read_b128 / b64
 // (lane groups of 16 / 32 need distinct 16-byte slots of a 256-byte bank row: a permutation inside aligned blocks keeps that), and
@@ -44,7 +33,7 @@ template<class TF> __device__ __forceinline__ C2<TF> gload_c2(const C2<TF>* base
 // fp64 (16-byte elements): 8-element blocks; fp32 (8-byte elements): 16-element blocks. No padding inside a row.
 // (Round-2 first form, i + i/8: conflict-free stores, but it shifted the slots of consecutive reads against their lane groups --
 // SQ_LDS_BANK_CONFLICT on 50-60 % of the LDS cycles of all three kernels.)
-template<class TF> __host__ __device__ __forceinline__ int lpad(int i)
+template<class TF> __host__ __device__ __forceinline__ int lds_slot(int i)
 {
     return sizeof(TF) == 8 ? (i ^ ((i >> 3) & 7)) : (i ^ ((i >> 4) & 15));
 }
@@ -73,7 +62,7 @@ template<int S, class TF> __device__ __forceinline__ void dft8(C2<TF> (&v)[8])
     v[0] = t0; v[2] = t1; v[4] = t2; v[6] = t3; v[1] = u0; v[3] = u1; v[5] = u2; v[7] = u3;
 }
 
-// One Stockham pass over a transform of N = 2^n points that lives in LDS at D[lpad<TF>(0..N-1)], done by N/8 threads (l = 0..N/8-1),
+// One Stockham pass over a transform of N = 2^n points that lives in LDS at D[lds_slot<TF>(0..N-1)], done by N/8 threads (l = 0..N/8-1),
 // every thread owning eight elements. gather: all reads of the pass; scatter: twiddles, butterflies of radix 2^lr (8 / lr of them
 // per thread), writes. The caller puts a barrier between the two and after. ls = log2 of the product of the radices already done.
 // T[m << tshift] = exp(-2 pi i m / N).
@@ -81,7 +70,7 @@ template<class TF> __device__ __forceinline__ void fft_gather(const C2<TF>* D, i
 {
     const int n8 = 1 << (n-3);
 #pragma unroll
-    for (int m=0; m<8; ++m) v[m] = D[lpad<TF>(l + m*n8)];
+    for (int m=0; m<8; ++m) v[m] = D[lds_slot<TF>(l + m*n8)];
 }
 template<int S, class TF> __device__ __forceinline__ void fft_scatter(C2<TF>* D, const C2<TF>* T, int tshift, int l, int n, int lr, int ls, C2<TF> (&v)[8])
 {
@@ -97,7 +86,7 @@ template<int S, class TF> __device__ __forceinline__ void fft_scatter(C2<TF>* D,
         dft8<S>(v);
         const int o = ((l - k) << 3) + k;
 #pragma unroll
-        for (int r=0; r<8; ++r) D[lpad<TF>(o + (r << ls))] = v[r];
+        for (int r=0; r<8; ++r) D[lds_slot<TF>(o + (r << ls))] = v[r];
     }
     else if (lr == 2)
     {
@@ -109,7 +98,7 @@ template<int S, class TF> __device__ __forceinline__ void fft_scatter(C2<TF>* D,
             if (ls > 0) { a1 = mul_tw<S>(a1, T[k << q]); a2 = mul_tw<S>(a2, T[(2*k) << q]); a3 = mul_tw<S>(a3, T[(3*k) << q]); }
             dft4<S>(a0, a1, a2, a3);
             const int o = ((j - k) << 2) + k;
-            D[lpad<TF>(o)] = a0; D[lpad<TF>(o + (1 << ls))] = a1; D[lpad<TF>(o + (2 << ls))] = a2; D[lpad<TF>(o + (3 << ls))] = a3;
+            D[lds_slot<TF>(o)] = a0; D[lds_slot<TF>(o + (1 << ls))] = a1; D[lds_slot<TF>(o + (2 << ls))] = a2; D[lds_slot<TF>(o + (3 << ls))] = a3;
         }
     }
     else
@@ -121,7 +110,7 @@ template<int S, class TF> __device__ __forceinline__ void fft_scatter(C2<TF>* D,
             C2<TF> a0 = v[b], a1 = v[b+4];
             if (ls > 0) a1 = mul_tw<S>(a1, T[k << q]);
             const int o = ((j - k) << 1) + k;
-            D[lpad<TF>(o)] = a0 + a1; D[lpad<TF>(o + (1 << ls))] = a0 - a1;
+            D[lds_slot<TF>(o)] = a0 + a1; D[lds_slot<TF>(o + (1 << ls))] = a0 - a1;
         }
     }
 }
@@ -191,7 +180,7 @@ __device__ __forceinline__ void fft_batch_ct(C2<TF>* D, const C2<TF>* T, int tsh
                         dft8<S>(v);
                         const int k = l & ((1 << F::ls(p)) - 1), o = ((l - k) << 3) + k;
 #pragma unroll
-                        for (int r=0; r<8; ++r) D[lpad<TF>(o + (r << F::ls(p)))] = v[r];
+                        for (int r=0; r<8; ++r) D[lds_slot<TF>(o + (r << F::ls(p)))] = v[r];
                     }
                     else fft_scatter<S>(D, T, tshift, l, NLOG, F::lr(0), 0, v);
                 }
@@ -275,7 +264,7 @@ __global__ void __launch_bounds__(BT) pres_in_fftx_kernel(const PresLdsIn<TF> a)
                            + rk * ( (vvt[r+1] + vv[r+1] * a.dti) - (vvt[r] + vv[r] * a.dti) ) * g.dyi_t
                            + ( up - low[h + r] ) * dzi;
                 low[h + r] = up;
-                Dr[2*((h + r)*rp + lpad<TF>(tid >> 1)) + (tid & 1)] = d;
+                Dr[2*((h + r)*rp + lds_slot<TF>(tid >> 1)) + (tid & 1)] = d;
             }
             sched_fence();
         }
@@ -287,7 +276,7 @@ __global__ void __launch_bounds__(BT) pres_in_fftx_kernel(const PresLdsIn<TF> a)
         for (int e=tid; e<8*nh; e+=itot)
         {
             const int kx = e >> 3, r = e & 7;
-            const C2<TF> za = D[r*rp + lpad<TF>(kx)], zb = D[r*rp + lpad<TF>((nh - kx) & (nh-1))];
+            const C2<TF> za = D[r*rp + lds_slot<TF>(kx)], zb = D[r*rp + lds_slot<TF>((nh - kx) & (nh-1))];
             const C2<TF> ev{TF(0.5)*(za.x + zb.x), TF(0.5)*(za.y - zb.y)};         // (Za + conj Zb) / 2
             const C2<TF> od{TF(0.5)*(za.y + zb.y), TF(0.5)*(zb.x - za.x)};         // (Za - conj Zb) / (2 i)
             C2<TF> x = ev + mul_tw<-1>(od, T[kx]);
@@ -389,7 +378,7 @@ __global__ void __launch_bounds__(BT) pres_ysolve_kernel(const PresLdsSolve<TF> 
     {
         const int k0 = rd << 3;
 #pragma unroll
-        for (int m=0; m<8; ++m) D[m*rp + lpad<TF>(ky)] = q[m];
+        for (int m=0; m<8; ++m) D[m*rp + lds_slot<TF>(ky)] = q[m];
         if (rd + 1 < nround)
         {
 #pragma unroll
@@ -402,10 +391,10 @@ __global__ void __launch_bounds__(BT) pres_ysolve_kernel(const PresLdsSolve<TF> 
 #pragma unroll
         for (int m=0; m<8; ++m)
         {
-            C2<TF> r = D[m*rp + lpad<TF>(ky)];
+            C2<TF> r = D[m*rp + lds_slot<TF>(ky)];
             if (packed && !two)
             {
-                const C2<TF> zm = D[m*rp + lpad<TF>(mir)];
+                const C2<TF> zm = D[m*rp + lds_slot<TF>(mir)];
                 r = upper ? C2<TF>{TF(0.5)*(zm.y + r.y), TF(0.5)*(r.x - zm.x)}       // Y_nyq[N-ky] = (Z[N-ky] - conj Z[ky]) / 2i
                           : C2<TF>{TF(0.5)*(r.x + zm.x), TF(0.5)*(r.y - zm.y)};      // Y_0[ky]     = (Z[ky] + conj Z[N-ky]) / 2
             }
@@ -470,7 +459,7 @@ __global__ void __launch_bounds__(BT) pres_ysolve_kernel(const PresLdsSolve<TF> 
                 if (k < kmax-1) { r.x -= w3[m]*pp.x; r.y -= (two ? w3b[m] : w3[m])*pp.y; }
                 pp = r;
             }
-            D[m*rp + lpad<TF>(ky)] = r;
+            D[m*rp + lds_slot<TF>(ky)] = r;
         }
         if (rd > 0)
         {
@@ -488,18 +477,18 @@ __global__ void __launch_bounds__(BT) pres_ysolve_kernel(const PresLdsSolve<TF> 
 #pragma unroll
             for (int m=0; m<8; ++m)
             {
-                const C2<TF> own = D[m*rp + lpad<TF>(ky)], mv = D[m*rp + lpad<TF>(mir)];
+                const C2<TF> own = D[m*rp + lds_slot<TF>(ky)], mv = D[m*rp + lds_slot<TF>(mir)];
                 z[m] = two ? own : (upper ? C2<TF>{mv.x + own.y, own.x - mv.y} : C2<TF>{own.x - mv.y, own.y + mv.x});
             }
             __syncthreads();
 #pragma unroll
-            for (int m=0; m<8; ++m) D[m*rp + lpad<TF>(ky)] = z[m];
+            for (int m=0; m<8; ++m) D[m*rp + lds_slot<TF>(ky)] = z[m];
             __syncthreads();
         }
         fft_batch_ct<+1, (BT <= 512), NY, TWC>(D + slot*rp, T, 0, l, a.ny, true, tw);
         if (BT <= 512) __syncthreads();
 #pragma unroll
-        for (int m=0; m<8; ++m) if (k0 + m < kmax) Sc[(size_t)(k0 + m)*lev] = D[m*rp + lpad<TF>(ky)];
+        for (int m=0; m<8; ++m) if (k0 + m < kmax) Sc[(size_t)(k0 + m)*lev] = D[m*rp + lds_slot<TF>(ky)];
         __syncthreads();
     }
 }
@@ -547,33 +536,33 @@ __global__ void __launch_bounds__(BT) pres_ifftx_out_kernel(const PresLdsOut<TF>
         {
             const int kx = e / 9, r = e - 9*kx;
             const int j = (r == 0) ? jsouth : j0 + r - 1;
-            D[r*rp + lpad<TF>(kx)] = a.S[((size_t)k*nh + kx)*jtot + j];
+            D[r*rp + lds_slot<TF>(kx)] = a.S[((size_t)k*nh + kx)*jtot + j];
         }
         __syncthreads();
         // complex-to-real: Z[kx] = (Xa + conj Xb) + i (Xa - conj Xb) exp(+2 pi i kx / itot), Xb = X[nh - kx]; pairs (kx, nh - kx) in place
         for (int e=tid; e<9*(nh/2 + 1); e+=itot)
         {
             const int r = e / (nh/2 + 1), kx = e - r*(nh/2 + 1), kb = nh - kx;
-            const C2<TF> xa = D[r*rp + lpad<TF>(kx)], xb = D[r*rp + lpad<TF>(kb & (nh-1))];
+            const C2<TF> xa = D[r*rp + lds_slot<TF>(kx)], xb = D[r*rp + lds_slot<TF>(kb & (nh-1))];
             if (kx == 0) D[r*rp] = C2<TF>{xa.x + xa.y, xa.x - xa.y};                // X_0 and X_nyq are real: Z[0] = (X_0 + X_nyq) + i (X_0 - X_nyq)
             else
             {
                 const C2<TF> ev{xa.x + xb.x, xa.y - xb.y}, df{xa.x - xb.x, xa.y + xb.y};
                 const C2<TF> od = mul_tw<+1>(df, T[kx]);
-                D[r*rp + lpad<TF>(kx)] = C2<TF>{ev.x - od.y, ev.y + od.x};
+                D[r*rp + lds_slot<TF>(kx)] = C2<TF>{ev.x - od.y, ev.y + od.x};
             }
             if (kx != 0 && kb != kx)
             {
                 const C2<TF> ev{xb.x + xa.x, xb.y - xa.y}, df{xb.x - xa.x, xb.y + xa.y};
                 const C2<TF> od = mul_tw<+1>(df, T[kb]);
-                D[r*rp + lpad<TF>(kb)] = C2<TF>{ev.x - od.y, ev.y + od.x};
+                D[r*rp + lds_slot<TF>(kb)] = C2<TF>{ev.x - od.y, ev.y + od.x};
             }
         }
         __syncthreads();
         { const C2<TF> none[fft_np(NX)][7] = {}; fft_batch_ct<+1, true, NX, false>(D + (active ? slot : 0)*rp, T, 1, l, a.nx, active, none); }
         __syncthreads();
-        // rows of p: element i of row r at real index 2*lpad<TF>(i/2) + (i&1)
-        const int oc = 2*lpad<TF>(tid >> 1) + (tid & 1), ow = 2*lpad<TF>(iw >> 1) + (iw & 1);
+        // rows of p: element i of row r at real index 2*lds_slot<TF>(i/2) + (i&1)
+        const int oc = 2*lds_slot<TF>(tid >> 1) + (tid & 1), ow = 2*lds_slot<TF>(iw >> 1) + (iw & 1);
         TF ps = Dr[2*(0*rp) + oc] * nrm;
 #pragma unroll
         for (int h=0; h<8; h+=RG)
