@@ -929,6 +929,7 @@ static int pres_lds_setup(mhh_pres_plan* P, const mhh_grid* g)
     if (!(is_pow2(P->itot) && P->itot >= 16 && P->itot <= LDS_BT && is_pow2(P->jtot) && P->jtot >= 8 && P->jtot <= 1024)) return MHH_OK;
     if (lds_bytes_x(P, 9) > lds_max || lds_bytes_y(P) > lds_max) return MHH_OK;
     if (g->igc > P->itot || g->jgc > P->jtot) return MHH_OK;
+    if ((long long)g->icells*g->jcells*g->kcells >= (1ll << 31)) return MHH_OK;        // the x-stage kernels index cells with 32 bits
     if (int e = (P->dtype == MHH_F64) ? pres_lds_setup_t<double>(P) : pres_lds_setup_t<float>(P)) return e;
     P->lds_ok = true;
     return MHH_OK;
