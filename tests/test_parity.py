@@ -487,6 +487,12 @@ def test_pres2_lds_transform_form(be, dtype):
         if kc: os.environ["MHH_PRES_LDS_KC"] = kc
         try:
             assert be.lib.mhh_pres_plan_has_lds_form(plan) == 1
+            assert be.lib.mhh_pres_exec_form(plan) == 0                  # small grid: mhh_pres_exec stays with the staged form ...
+            os.environ["MHH_PRES_LDS"] = "1"
+            assert be.lib.mhh_pres_exec_form(plan) == 1                  # ... unless told otherwise
+            os.environ["MHH_PRES_LDS"] = "0"
+            assert be.lib.mhh_pres_exec_form(plan) == 0
+            os.environ.pop("MHH_PRES_LDS")
             pk_want = np.zeros((g.ktot, g.jtot, g.itot), dtype=dtype)
             ut, vt, wt = c.ut.copy(), c.vt.copy(), c.wt.copy()
             O.orc_pres_input(Gh, 2, ptr(pk_want), ptr(c.u), ptr(c.v), ptr(c.w), ptr(ut), ptr(vt), ptr(wt), ptr(c.rhoref), ptr(c.rhorefh), dbl(dt))
