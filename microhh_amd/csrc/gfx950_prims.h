@@ -175,6 +175,11 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// Workgroup barrier for data exchanged through LDS only: waits for this wave's LDS traffic, not for its global loads and stores.
+// __syncthreads() is a release / acquire fence on ALL memory plus the barrier, i.e. s_waitcnt vmcnt(0) -- a kernel that requests
+// the next batch from global memory and then synchronises its waves on LDS data would wait out the full memory latency at that
+// barrier, and every store before one as well. (Global data written by one thread and read by ANOTHER needs __syncthreads.)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // v_rcp_f64 / v_rcp_f32: the hardware's reciprocal seed (refined by the caller)
 __device__ __forceinline__ double recip_seed(double x) { return __builtin_amdgcn_rcp(x); }
 __device__ __forceinline__ float  recip_seed(float x)  { return __builtin_amdgcn_rcpf(x); }

@@ -121,7 +121,7 @@ __device__ __forceinline__ int first_radix_log2(int n) { const int r = n % 3; re
 // thread works on transform D (of N/8 threads, as number l); idle threads only keep the count. WL: the N/8 threads of a transform
 // sit in one wave (N <= 512), so the passes need no block barrier at all -- the caller's barrier before (data in LDS) and after
 // (before other waves read the result) are the only ones.
-template<bool WL> __device__ __forceinline__ void fft_sync() { if (WL) wave_sync(); else __syncthreads(); }
+template<bool WL> __device__ __forceinline__ void fft_sync() { if (WL) wave_sync(); else lds_barrier(); }
 template<int S, bool WL, class TF> __device__ __forceinline__ void fft_batch(C2<TF>* D, const C2<TF>* T, int tshift, int l, int n, bool active)
 {
     C2<TF> v[8];
@@ -234,14 +234,14 @@ __global__ void __launch_bounds__(BT) pres_in_fftx_kernel(const PresLdsIn<TF> a)
     // the lower-face term of level k is the upper-face term of level k-1: carried
     TF low[8];
     {
-        const int c = c0 + (k0 + g.kgc)*kk; const TF rh = a.rhorefh[k0 + g.kgc];
+        const int c = c0 + (k0 + g.kgc)*kk; const TF rh = uniform_load(a.rhorefh, k0 + g.kgc);
 #pragma unroll
         for (int r=0; r<8; ++r) low[r] = rh * (a.wt[c + r*jj] + a.w[c + r*jj] * a.dti);
     }
     for (int k=k0; k<k1; ++k)
     {
         const int kd = k + g.kgc, c = c0 + kd*kk;
-        const TF rk = a.rhoref[kd], rhp = a.rhorefh[kd+1], dzi = g.dzi[kd];
+        const TF rk = uniform_load(a.rhoref, kd), rhp = uniform_load(a.rhorefh, kd+1), dzi = uniform_load(g.dzi, kd);
 #pragma unroll
         for (int h=0; h<8; h+=RG)                     // RG rows at a time: the loads of a group in flight together
         {
@@ -268,9 +268,9 @@ __global__ void __launch_bounds__(BT) pres_in_fftx_kernel(const PresLdsIn<TF> a)
             }
             sched_fence();
         }
-        __syncthreads();
+        lds_barrier();
         { const C2<TF> none[fft_np(NX)][7] = {}; fft_batch_ct<-1, true, NX, false>(D + (active ? slot : 0)*rp, T, 1, l, a.nx, active, none); }
-        __syncthreads();
+        lds_barrier();
         // real-to-complex: X[kx] = E + exp(-2 pi i kx / itot) O from Z[kx] and Z[nh - kx]; one (kx, row) element per thread and turn,
         // rows fastest: eight neighbouring threads write one 128-byte (fp64) piece of S[k][kx][j0..j0+7]
         for (int e=tid; e<8*nh; e+=itot)
@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(BT) pres_in_fftx_kernel(const PresLdsIn<TF> a)
             if (kx == 0) x = C2<TF>{za.x + za.y, za.x - za.y};                      // (X_0, X_nyq): both real, one column
             a.S[((size_t)k*nh + kx)*jtot + j0 + r] = x;
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 
@@ -312,13 +312,26 @@ template<class TF> __device__ __forceinline__ TF recip(TF x)
     e = tfma(-x, y, TF(1));    y = tfma(y, e, y);
     return y;
 }
+// the diagonal of level k from its table entries (src/pres_2.cxx:289-330)
+template<class TF>
+__device__ __forceinline__ TF tdma_diag_vals(TF dz2, TF rho, TF ak, TF ck, TF bm, bool mean, int k, int kmax)
+{
+    TF b = dz2 * rho*bm - (ak+ck);
+    if (k == 0) b += ak;
+    if (k == kmax-1) { if (mean) b -= ck; else b += ck; }
+    return b;
+}
 template<class TF>
 __device__ __forceinline__ TF tdma_diag_lds(const PresLdsSolve<TF>& a, TF bm, bool mean, int k)
 {
-    const TF dz2 = a.dz[k]*a.dz[k];
-    TF b = dz2 * a.rho[k]*bm - (a.a[k]+a.c[k]);
-    if (k == 0) b += a.a[0];
-    if (k == a.kmax-1) { if (mean) b -= a.c[k]; else b += a.c[k]; }
+    // per-level tables through the scalar cache (uniform_load): as plain loads they become VECTOR loads of a uniform address, each
+    // followed by s_waitcnt vmcnt(0) -- which also waits for the rows requested for the next round and for the stores of the last
+    // level: eight full memory latencies per round (the y stage ran at 1.05 ms with them)
+    const TF dzk = uniform_load(a.dz, k), ak = uniform_load(a.a, k), ck = uniform_load(a.c, k);
+    const TF dz2 = dzk*dzk;
+    TF b = dz2 * uniform_load(a.rho, k)*bm - (ak+ck);
+    if (k == 0) b += ak;
+    if (k == a.kmax-1) { if (mean) b -= ck; else b += ck; }
     return b;
 }
 // which mode thread ky of block kx solves: its bmati index
@@ -338,9 +351,9 @@ __global__ void __launch_bounds__(64) pres_lds_factor_kernel(TF* __restrict__ W3
     W3[col] = TF(0);
     for (int k=1; k<a.kmax; ++k)
     {
-        const TF w3 = a.c[k-1] * inv;
+        const TF w3 = uniform_load(a.c, k-1) * inv;
         W3[col + k*lev] = w3;
-        inv = recip(tdma_diag_lds(a, bm, mean, k) - a.a[k]*w3);
+        inv = recip(tdma_diag_lds(a, bm, mean, k) - uniform_load(a.a, k)*w3);
     }
 }
 template<class TF, int BT, int NY>
@@ -355,7 +368,7 @@ __global__ void __launch_bounds__(BT) pres_ysolve_kernel(const PresLdsSolve<TF> 
     const int team = N >> 3, slot = ky / team, l = ky - slot*team;        // slot < 8 always
     constexpr bool TWC = (NY > 0 && BT <= 512);                           // twiddles in registers where the register file has the room
     C2<TF> tw[fft_np(NY)][7];
-    if constexpr (TWC) { __syncthreads(); fft_twiddles_ct<NY>(T, 0, l, tw); }
+    if constexpr (TWC) { lds_barrier(); fft_twiddles_ct<NY>(T, 0, l, tw); }
     const size_t lev = (size_t)a.ncol*N, wlev = (size_t)(a.ncol + 1)*N;
     C2<TF>* Sc = a.S + (size_t)kx*N + ky;
     const TF* Wc = a.W3 + (size_t)kx*N + ky;
@@ -384,9 +397,9 @@ __global__ void __launch_bounds__(BT) pres_ysolve_kernel(const PresLdsSolve<TF> 
 #pragma unroll
             for (int m=0; m<8; ++m) if (k0 + 8 + m < kmax) q[m] = Sc[(size_t)(k0 + 8 + m)*lev];
         }
-        __syncthreads();
+        lds_barrier();
         fft_batch_ct<-1, (BT <= 512), NY, TWC>(D + slot*rp, T, 0, l, a.ny, true, tw);
-        if (BT <= 512) __syncthreads();
+        if (BT <= 512) lds_barrier();
         C2<TF> r8[8];
 #pragma unroll
         for (int m=0; m<8; ++m)
@@ -400,34 +413,49 @@ __global__ void __launch_bounds__(BT) pres_ysolve_kernel(const PresLdsSolve<TF> 
             }
             r8[m] = r;
         }
-        __syncthreads();
+        lds_barrier();
+        // four levels at a time: their table entries are requested together (scalar loads, clamped indices: no branch between
+        // them), then the dependent chain runs
 #pragma unroll
-        for (int m=0; m<8; ++m)
+        for (int h=0; h<8; h+=4)
         {
-            const int k = k0 + m;
-            if (k < kmax)
+            TF dzv[4], av[4], cv[4], rv[4];
+#pragma unroll
+            for (int n=0; n<4; ++n)
             {
-                const TF dz2 = a.dz[k]*a.dz[k];
-                TF w2 = tdma_diag_lds(a, bm, mean, k);
-                C2<TF> r = r8[m];
-                r.x = dz2 * r.x; r.y = dz2 * r.y;
-                if (k > 0)
+                const int kc = (k0 + h + n < kmax) ? k0 + h + n : kmax - 1;
+                dzv[n] = uniform_load(a.dz, kc); av[n] = uniform_load(a.a, kc); cv[n] = uniform_load(a.c, kc); rv[n] = uniform_load(a.rho, kc);
+            }
+            TF cprev = uniform_load(a.c, (k0 + h > 0) ? k0 + h - 1 : 0);
+#pragma unroll
+            for (int n=0; n<4; ++n)
+            {
+                const int m = h + n, k = k0 + m;
+                if (k < kmax)
                 {
-                    w2 -= a.a[k] * (a.c[k-1] * inv);
-                    r.x -= a.a[k]*pp.x; r.y -= a.a[k]*pp.y;
+                    const TF dz2 = dzv[n]*dzv[n], ak = av[n];
+                    TF w2 = tdma_diag_vals(dz2, rv[n], ak, cv[n], bm, mean, k, kmax);
+                    C2<TF> r = r8[m];
+                    r.x = dz2 * r.x; r.y = dz2 * r.y;
+                    if (k > 0)
+                    {
+                        w2 -= ak * (cprev * inv);
+                        r.x -= ak*pp.x; r.y -= ak*pp.y;
+                    }
+                    inv = recip(w2);
+                    r.x *= inv;
+                    if (two)
+                    {
+                        TF w2b = tdma_diag_vals(dz2, rv[n], ak, cv[n], bm2, false, k, kmax);
+                        if (k > 0) w2b -= ak * (cprev * inv2);
+                        inv2 = recip(w2b);
+                        r.y *= inv2;
+                    }
+                    else r.y *= inv;
+                    pp = r;
+                    Sc[(size_t)k*lev] = r;
                 }
-                inv = recip(w2);
-                r.x *= inv;
-                if (two)
-                {
-                    TF w2b = tdma_diag_lds(a, bm2, false, k);
-                    if (k > 0) w2b -= a.a[k] * (a.c[k-1] * inv2);
-                    inv2 = recip(w2b);
-                    r.y *= inv2;
-                }
-                else r.y *= inv;
-                pp = r;
-                Sc[(size_t)k*lev] = r;
+                cprev = cv[n];
             }
         }
     }
@@ -470,7 +498,7 @@ __global__ void __launch_bounds__(BT) pres_ysolve_kernel(const PresLdsSolve<TF> 
                 if (two) w3b[m] = Wc2[(size_t)(k0 - 8 + m + 1)*wlev];
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (packed)                        // Z[ky] = Y_0[ky] + i Y_nyq[ky] again, the upper half from the Hermitian symmetry of both
         {
             C2<TF> z[8];
@@ -480,16 +508,16 @@ __global__ void __launch_bounds__(BT) pres_ysolve_kernel(const PresLdsSolve<TF> 
                 const C2<TF> own = D[m*rp + lds_slot<TF>(ky)], mv = D[m*rp + lds_slot<TF>(mir)];
                 z[m] = two ? own : (upper ? C2<TF>{mv.x + own.y, own.x - mv.y} : C2<TF>{own.x - mv.y, own.y + mv.x});
             }
-            __syncthreads();
+            lds_barrier();
 #pragma unroll
             for (int m=0; m<8; ++m) D[m*rp + lds_slot<TF>(ky)] = z[m];
-            __syncthreads();
+            lds_barrier();
         }
         fft_batch_ct<+1, (BT <= 512), NY, TWC>(D + slot*rp, T, 0, l, a.ny, true, tw);
-        if (BT <= 512) __syncthreads();
+        if (BT <= 512) lds_barrier();
 #pragma unroll
         for (int m=0; m<8; ++m) if (k0 + m < kmax) Sc[(size_t)(k0 + m)*lev] = D[m*rp + lds_slot<TF>(ky)];
-        __syncthreads();
+        lds_barrier();
     }
 }
 
@@ -531,6 +559,7 @@ __global__ void __launch_bounds__(BT) pres_ifftx_out_kernel(const PresLdsOut<TF>
     {
         const bool emit = (k >= k0);
         const int c = (tid + g.igc) + (j0 + g.jgc)*jj + (k + g.kgc)*kk;
+        const TF dzhi_k = uniform_load(g.dzhi, k + g.kgc);
         // spectral rows -> LDS (columns 0 .. nh-1, column 0 = (X_0, X_nyq); rows fastest in memory)
         for (int e=tid; e<9*nh; e+=itot)
         {
@@ -538,7 +567,7 @@ __global__ void __launch_bounds__(BT) pres_ifftx_out_kernel(const PresLdsOut<TF>
             const int j = (r == 0) ? jsouth : j0 + r - 1;
             D[r*rp + lds_slot<TF>(kx)] = a.S[((size_t)k*nh + kx)*jtot + j];
         }
-        __syncthreads();
+        lds_barrier();
         // complex-to-real: Z[kx] = (Xa + conj Xb) + i (Xa - conj Xb) exp(+2 pi i kx / itot), Xb = X[nh - kx]; pairs (kx, nh - kx) in place
         for (int e=tid; e<9*(nh/2 + 1); e+=itot)
         {
@@ -558,9 +587,9 @@ __global__ void __launch_bounds__(BT) pres_ifftx_out_kernel(const PresLdsOut<TF>
                 D[r*rp + lds_slot<TF>(kb)] = C2<TF>{ev.x - od.y, ev.y + od.x};
             }
         }
-        __syncthreads();
+        lds_barrier();
         { const C2<TF> none[fft_np(NX)][7] = {}; fft_batch_ct<+1, true, NX, false>(D + (active ? slot : 0)*rp, T, 1, l, a.nx, active, none); }
-        __syncthreads();
+        lds_barrier();
         // rows of p: element i of row r at real index 2*lds_slot<TF>(i/2) + (i&1)
         const int oc = 2*lds_slot<TF>(tid >> 1) + (tid & 1), ow = 2*lds_slot<TF>(iw >> 1) + (iw & 1);
         TF ps = Dr[2*(0*rp) + oc] * nrm;
@@ -584,7 +613,7 @@ __global__ void __launch_bounds__(BT) pres_ifftx_out_kernel(const PresLdsOut<TF>
                     const TF pb = (k == 0) ? pc : below[r];                          // p[kstart-1] = p[kstart]
                     a.ut[cr] = tu[q] - (pc - pw) * g.dxi_t;
                     a.vt[cr] = tv[q] - (pc - ps) * g.dyi_t;
-                    a.wt[cr] = tw[q] - (pc - pb) * g.dzhi[k + g.kgc];
+                    a.wt[cr] = tw[q] - (pc - pb) * dzhi_k;
                     // p: the cell, its images in the periodic halo, and the ghost level below the first one
                     const int js = j0 + r;
                     for (int lv=0; lv<2; ++lv)
@@ -607,7 +636,7 @@ __global__ void __launch_bounds__(BT) pres_ifftx_out_kernel(const PresLdsOut<TF>
             }
             sched_fence();
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 

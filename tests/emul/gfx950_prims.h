@@ -26,6 +26,7 @@ template<int PB> inline void lds_dma_sv(const void*, unsigned, unsigned) {}
 template<int PB> inline void lds_dma_sv2(const void*, unsigned, unsigned, unsigned) {}
 template<class T> inline T sgpr(T x) { return x; }
 inline void sched_fence() {}
+inline void lds_barrier() { __syncthreads(); }
 inline void wave_sync() { __syncthreads(); }     // every thread of the block reaches the same wave_sync calls (uniform control flow)
 inline double recip_seed(double x) { return 1./x; }
 inline float  recip_seed(float x)  { return 1.f/x; }
