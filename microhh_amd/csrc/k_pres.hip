@@ -888,7 +888,8 @@ static constexpr int LDS_RG = MHH_PRES_LDS_RG, LDS_BT = MHH_PRES_LDS_BT;
 // jtot = 512 (at 1024 the unrolled passes no longer fit the 128 registers of a 1024-thread block). Everything else runs the same kernels with the sizes as run-time values.
 template<class TF> static constexpr int lds_nx_ct() { return sizeof(TF) == 8 ? 8 : 9; }
 static int ilog2(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
-static size_t lds_bytes_x(const mhh_pres_plan* P, int rows) { return ((size_t)rows*(P->itot/2 + 2) + P->itot) * 2*P->esz; }
+// rows of the transforms + the twiddle table; the 9-row kernel (stage 3) also keeps p of the level below there (8 rows of itot reals)
+static size_t lds_bytes_x(const mhh_pres_plan* P, int rows) { return ((size_t)rows*(P->itot/2 + 2) + P->itot) * 2*P->esz + (rows == 9 ? (size_t)8*P->itot*P->esz : 0); }
 static size_t lds_bytes_y(const mhh_pres_plan* P)           { return ((size_t)8*P->jtot + P->jtot) * 2*P->esz; }
 template<class TF>
 static lds_fft::PresLdsSolve<TF> lds_solve_args(const mhh_pres_plan* P)

@@ -269,11 +269,14 @@ __global__ void __launch_bounds__(BT) pres_in_fftx_kernel(const PresLdsIn<TF> a)
             sched_fence();
         }
         lds_barrier();
-        { const C2<TF> none[fft_np(NX)][7] = {}; fft_batch_ct<-1, true, NX, false>(D + (active ? slot : 0)*rp, T, 1, l, a.nx, active, none); }
+        // opaque per-level copies of the thread's indices: their address arithmetic stays inside the level instead of being hoisted
+        // out of the loop into registers the transform then spills (see pres_ifftx_out_kernel)
+        unsigned tl = (unsigned)tid, ll = (unsigned)l, sl = (unsigned)(active ? slot : 0); keep_vgpr(tl); keep_vgpr(ll); keep_vgpr(sl);
+        { const C2<TF> none[fft_np(NX)][7] = {}; fft_batch_ct<-1, true, NX, false>(D + sl*rp, T, 1, (int)ll, a.nx, active, none); }
         lds_barrier();
         // real-to-complex: X[kx] = E + exp(-2 pi i kx / itot) O from Z[kx] and Z[nh - kx]; one (kx, row) element per thread and turn,
         // rows fastest: eight neighbouring threads write one 128-byte (fp64) piece of S[k][kx][j0..j0+7]
-        for (int e=tid; e<8*nh; e+=itot)
+        for (int e=(int)tl; e<8*nh; e+=itot)
         {
             const int kx = e >> 3, r = e & 7;
             const C2<TF> za = D[r*rp + lds_slot<TF>(kx)], zb = D[r*rp + lds_slot<TF>((nh - kx) & (nh-1))];
@@ -398,7 +401,8 @@ __global__ void __launch_bounds__(BT) pres_ysolve_kernel(const PresLdsSolve<TF> 
             for (int m=0; m<8; ++m) if (k0 + 8 + m < kmax) q[m] = Sc[(size_t)(k0 + 8 + m)*lev];
         }
         lds_barrier();
-        fft_batch_ct<-1, (BT <= 512), NY, TWC>(D + slot*rp, T, 0, l, a.ny, true, tw);
+        { unsigned ll = (unsigned)l, sl = (unsigned)slot; keep_vgpr(ll); keep_vgpr(sl);       // per-round copies: see pres_ifftx_out_kernel
+          fft_batch_ct<-1, (BT <= 512), NY, TWC>(D + sl*rp, T, 0, (int)ll, a.ny, true, tw); }
         if (BT <= 512) lds_barrier();
         C2<TF> r8[8];
 #pragma unroll
@@ -513,7 +517,8 @@ __global__ void __launch_bounds__(BT) pres_ysolve_kernel(const PresLdsSolve<TF> 
             for (int m=0; m<8; ++m) D[m*rp + lds_slot<TF>(ky)] = z[m];
             lds_barrier();
         }
-        fft_batch_ct<+1, (BT <= 512), NY, TWC>(D + slot*rp, T, 0, l, a.ny, true, tw);
+        { unsigned ll = (unsigned)l, sl = (unsigned)slot; keep_vgpr(ll); keep_vgpr(sl);
+          fft_batch_ct<+1, (BT <= 512), NY, TWC>(D + sl*rp, T, 0, (int)ll, a.ny, true, tw); }
         if (BT <= 512) lds_barrier();
 #pragma unroll
         for (int m=0; m<8; ++m) if (k0 + m < kmax) Sc[(size_t)(k0 + m)*lev] = D[m*rp + lds_slot<TF>(ky)];
@@ -552,16 +557,20 @@ __global__ void __launch_bounds__(BT) pres_ifftx_out_kernel(const PresLdsOut<TF>
     const TF nrm = (TF(1) / TF(jtot)) * (TF(1) / TF(itot));           // both powers of two: exact
     const int jsouth = (j0 + jtot - 1) & (jtot - 1);
     const int iw = (tid + itot - 1) & (itot - 1);
-    TF below[8];
-#pragma unroll
-    for (int r=0; r<8; ++r) below[r] = TF(0);
+    // p of the level below, eight rows of this thread's column: in LDS rather than in sixteen registers (see the note on spills below)
+    TF* below = reinterpret_cast<TF*>(T + itot) + tid;               // below[r*itot]
     for (int k = (k0 > 0 ? k0-1 : 0); k<k1; ++k)
     {
         const bool emit = (k >= k0);
         const int c = (tid + g.igc) + (j0 + g.jgc)*jj + (k + g.kgc)*kk;
         const TF dzhi_k = uniform_load(g.dzhi, k + g.kgc);
+        // The index arithmetic below depends on the thread only; hoisted out of the level loop it occupies registers across the
+        // transform, which then spills -- and every reload of a spilled register is a scratch load followed by s_waitcnt vmcnt(0),
+        // i.e. a wait for every tendency store still in flight (cycle stamps: the transform of a level took 31 600 of its 62 600
+        // cycles). An opaque copy of the thread index per level keeps that arithmetic inside the level.
+        unsigned tl = (unsigned)tid; keep_vgpr(tl);
         // spectral rows -> LDS (columns 0 .. nh-1, column 0 = (X_0, X_nyq); rows fastest in memory)
-        for (int e=tid; e<9*nh; e+=itot)
+        for (int e=(int)tl; e<9*nh; e+=itot)
         {
             const int kx = e / 9, r = e - 9*kx;
             const int j = (r == 0) ? jsouth : j0 + r - 1;
@@ -569,7 +578,7 @@ __global__ void __launch_bounds__(BT) pres_ifftx_out_kernel(const PresLdsOut<TF>
         }
         lds_barrier();
         // complex-to-real: Z[kx] = (Xa + conj Xb) + i (Xa - conj Xb) exp(+2 pi i kx / itot), Xb = X[nh - kx]; pairs (kx, nh - kx) in place
-        for (int e=tid; e<9*(nh/2 + 1); e+=itot)
+        for (int e=(int)tl; e<9*(nh/2 + 1); e+=itot)
         {
             const int r = e / (nh/2 + 1), kx = e - r*(nh/2 + 1), kb = nh - kx;
             const C2<TF> xa = D[r*rp + lds_slot<TF>(kx)], xb = D[r*rp + lds_slot<TF>(kb & (nh-1))];
@@ -588,7 +597,8 @@ __global__ void __launch_bounds__(BT) pres_ifftx_out_kernel(const PresLdsOut<TF>
             }
         }
         lds_barrier();
-        { const C2<TF> none[fft_np(NX)][7] = {}; fft_batch_ct<+1, true, NX, false>(D + (active ? slot : 0)*rp, T, 1, l, a.nx, active, none); }
+        { unsigned ll = (unsigned)l, sl = (unsigned)(active ? slot : 0); keep_vgpr(ll); keep_vgpr(sl);      // likewise: the transform's addresses
+          const C2<TF> none[fft_np(NX)][7] = {}; fft_batch_ct<+1, true, NX, false>(D + sl*rp, T, 1, (int)ll, a.nx, active, none); }
         lds_barrier();
         // rows of p: element i of row r at real index 2*lds_slot<TF>(i/2) + (i&1)
         const int oc = 2*lds_slot<TF>(tid >> 1) + (tid & 1), ow = 2*lds_slot<TF>(iw >> 1) + (iw & 1);
@@ -610,7 +620,7 @@ __global__ void __launch_bounds__(BT) pres_ifftx_out_kernel(const PresLdsOut<TF>
                 if (emit)
                 {
                     const int cr = c + r*jj;
-                    const TF pb = (k == 0) ? pc : below[r];                          // p[kstart-1] = p[kstart]
+                    const TF pb = (k == 0) ? pc : below[r*itot];                          // p[kstart-1] = p[kstart]
                     a.ut[cr] = tu[q] - (pc - pw) * g.dxi_t;
                     a.vt[cr] = tv[q] - (pc - ps) * g.dyi_t;
                     a.wt[cr] = tw[q] - (pc - pb) * dzhi_k;
@@ -632,7 +642,7 @@ __global__ void __launch_bounds__(BT) pres_ifftx_out_kernel(const PresLdsOut<TF>
                         }
                     }
                 }
-                below[r] = pc; ps = pc;
+                below[r*itot] = pc; ps = pc;
             }
             sched_fence();
         }
