@@ -248,11 +248,22 @@ __global__ void __launch_bounds__(256) xbuf_y_kernel(C2<TF>* __restrict__ specy,
     const size_t sy0 = (size_t)k*nxb*jtot + (size_t)r*jmax;      // specy element (k, kxl=0, j=r*jmax)
     if (FWD)
     {
+        // all eight loads of a thread are requested before the first is used (clamped addresses, no branch between them): as
+        // load - store pairs under a condition they were eight memory round trips in a row
+        C2<TF> v[TJ*TX/256];
+#pragma unroll
         for (int p = 0; p < TJ*TX/256; ++p)                      // 8 passes: 8 rows x 32 columns each
         {
             const int row = p*8 + t/32, cx = t % 32;
             const int jl = jl0 + row, kxl = kx0 + cx;
-            if (jl < jmax && kxl < nxb) tile[row][cx] = xbuf[xb0 + (size_t)jl*nxb + kxl];
+            const bool in = (jl < jmax && kxl < nxb);
+            v[p] = xbuf[xb0 + (in ? (size_t)jl*nxb + kxl : (size_t)0)];
+        }
+#pragma unroll
+        for (int p = 0; p < TJ*TX/256; ++p)
+        {
+            const int row = p*8 + t/32, cx = t % 32;
+            if (jl0 + row < jmax && kx0 + cx < nxb) tile[row][cx] = v[p];
         }
         __syncthreads();
         for (int p = 0; p < TJ*TX/256; ++p)                      // 8 passes: 4 columns x 64 rows each
@@ -264,11 +275,20 @@ __global__ void __launch_bounds__(256) xbuf_y_kernel(C2<TF>* __restrict__ specy,
     }
     else
     {
+        C2<TF> v[TJ*TX/256];
+#pragma unroll
         for (int p = 0; p < TJ*TX/256; ++p)
         {
             const int cx = p*4 + t/64, row = t % 64;
             const int jl = jl0 + row, kxl = kx0 + cx;
-            if (jl < jmax && kxl < nxb) tile[row][cx] = specy[sy0 + (size_t)kxl*jtot + jl];
+            const bool in = (jl < jmax && kxl < nxb);
+            v[p] = specy[sy0 + (in ? (size_t)kxl*jtot + jl : (size_t)0)];
+        }
+#pragma unroll
+        for (int p = 0; p < TJ*TX/256; ++p)
+        {
+            const int cx = p*4 + t/64, row = t % 64;
+            if (jl0 + row < jmax && kx0 + cx < nxb) tile[row][cx] = v[p];
         }
         __syncthreads();
         for (int p = 0; p < TJ*TX/256; ++p)
