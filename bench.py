@@ -126,7 +126,7 @@ def cpu_baseline(case, sample=(256, 256, 256), reps=3, with_pres=True):
                       % (case, it, jt, kt, reps, os.cpu_count() or 0)}
 
 
-def recorded_traffic(workload):
+def recorded_traffic(workload, igc=None):
     """HBM bytes per launch of the dominant kernel from the newest profiles/*_traffic.json that scripts/gpu_traffic.sh wrote for
     this workload -- only if it was measured on the sources this run was built from (microhh_amd/stamp.py)."""
     import glob
@@ -137,7 +137,7 @@ def recorded_traffic(workload):
             d = json.load(open(f))
         except (OSError, ValueError):
             continue
-        if d.get("workload") == workload and d.get("stamp") == source_stamp() and d.get("build", "default") == "default":
+        if d.get("workload") == workload and d.get("stamp") == source_stamp() and d.get("build", "default") == "default" and d.get("igc") == igc:
             best = (f, d)
     if best is None:
         return None, None
@@ -164,6 +164,9 @@ def main():
     ap.add_argument("--graph", action="store_true", help="N=1 on a GPU: the timed steps replay one hipGraph of a step (HotPath.capture_step); "
                     "the per-kernel event times then come from untimed call-by-call steps before them")
     ap.add_argument("--no-fma-line", action="store_true", help="skip the extra timing of the named FMA build (fma_build in the JSON line)")
+    ap.add_argument("--igc", type=int, default=None, help="ghost cells in x (>= the case's own): the layout the reference's grid takes when an operator "
+                    "calls Grid::set_minimum_ghost_cells (src/grid.cxx:435-439); 16 = rows of whole 128-byte lines at itot = 512 fp64. A second, NAMED line: "
+                    "the headline stays on the reference default")
     ap.add_argument("--force-slab", action="store_true", help="N=1 only: run the slab code path (halo pack/unpack, split pressure solve) with local copies as exchanges")
     args = ap.parse_args()
 
@@ -216,7 +219,7 @@ def main():
     from microhh_amd.model import HotPath
     rhs_only = args.workload in FP32_RHS_ONLY
     hp = HotPath(case, itot, jtot, ktot, device=("cuda:%d" % local if on_gpu else "cpu"), npy=world, rank=rank,   # slab in y: npx=1, npy=world
-                 force_slab=(args.force_slab and world == 1), dtype=(np.float32 if rhs_only else np.float64))
+                 force_slab=(args.force_slab and world == 1), dtype=(np.float32 if rhs_only else np.float64), igc=args.igc)
 
     rhs = hp.rhs_unfused if args.unfused else hp.rhs
 
@@ -290,7 +293,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32" if rhs_only else "f64", "data": "synthetic",
         "config": {"workload": desc, "grid": [itot, jtot, ktot], "decomposition": "slab-y npx=1 npy=%d" % world,
-                   "rhs": "unfused" if args.unfused else "fused", "halo_overlap": bool(overlapped), "launch": "hipGraph replay" if use_graph else "call by call"},
+                   "ghost_cells": [hp.grid.igc, hp.grid.jgc, hp.grid.kgc], "rhs": "unfused" if args.unfused else "fused", "halo_overlap": bool(overlapped), "launch": "hipGraph replay" if use_graph else "call by call"},
         "roofline": {"bound": "hbm", "kernel": "fused RHS (advec+diff) pass" if not args.unfused else "advec+diff launches",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None, "alg_bytes_per_cell": hp.alg_bytes_rhs(), "ms_per_launch": rhs_ms},
@@ -305,7 +308,7 @@ def main():
                            "form": "transforms in LDS, 3 kernels (csrc/pres_lds.h)" if hp.lib.mhh_pres_exec_form(hp.plan) == 1 else "staged, rocFFT (csrc/k_pres.hip)"}
     out["build"] = args.build if not os.environ.get("MHH_LIB") or args.build == "fma" else os.path.basename(os.environ["MHH_LIB"])
     if world == 1 and not args.unfused and out["build"] == "default":
-        out["roofline"]["traffic"], src = recorded_traffic(args.workload)      # FETCH_SIZE x 2 + WRITE_SIZE per launch, or null
+        out["roofline"]["traffic"], src = recorded_traffic(args.workload, args.igc)      # FETCH_SIZE x 2 + WRITE_SIZE per launch, or null
         if src:
             out["roofline"]["traffic_source"] = src
     if world == 1 and on_gpu and args.build == "default" and not args.unfused and not rhs_only and not args.no_fma_line and not os.environ.get("MHH_LIB") \

@@ -96,16 +96,18 @@ template<int PB> __device__ __forceinline__ void lds_dma_sv2(const void* uniform
         asm volatile("s_mov_b32 %0, m0\n\ts_add_u32 m0, %3, %4\n\ts_nop 2\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
                      : "=&s"(m0_saved) : "v"(lane_byte_offset), "s"(uniform_base), "s"(lds_wave_base), "s"(lds_offset) : "memory", "scc");
 #else
-    // M0 is left holding the LDS address: the compiler has no use of its own for M0 in these kernels (on gfx9 the ds_ instructions
-    // do not read it; no movrel, GWS, sendmsg or LDS-DMA builtin beside this primitive), and the two s_mov that saved and restored
-    // it around every copy were 18 of a level's ~180 scalar instructions (-DMHH_DMA_M0_SAVE brings them back)
+    // M0 is left holding the LDS address and DECLARED clobbered: the compiler saves and restores it around the statement only
+    // where it has a use of its own for M0 (in these kernels it has none: on gfx9 the ds_ instructions do not read it; no movrel,
+    // GWS, sendmsg or LDS-DMA builtin beside this primitive), so the two s_mov that an unconditional save / restore put around every
+    // copy (18 of a level's ~180 scalar instructions; -DMHH_DMA_M0_SAVE brings them back) are gone without an assumption about
+    // code generation
     (void)m0_saved;
     if constexpr (PB == 16)
         asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %0, %1"
-                     : : "v"(lane_byte_offset), "s"(uniform_base), "s"(lds_wave_base), "s"(lds_offset) : "memory", "scc");
+                     : : "v"(lane_byte_offset), "s"(uniform_base), "s"(lds_wave_base), "s"(lds_offset) : "memory", "scc", "m0");
     else
         asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 2\n\tglobal_load_lds_dword %0, %1"
-                     : : "v"(lane_byte_offset), "s"(uniform_base), "s"(lds_wave_base), "s"(lds_offset) : "memory", "scc");
+                     : : "v"(lane_byte_offset), "s"(uniform_base), "s"(lds_wave_base), "s"(lds_offset) : "memory", "scc", "m0");
 #endif
 }
 // Pin a wave-uniform value in scalar registers of its own. Kernel arguments arrive by merged s_load_dwordx8/x16, and the

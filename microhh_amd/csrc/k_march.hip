@@ -123,7 +123,9 @@ template<int E> __device__ __forceinline__ float scale2(float x)
 // separate calls then run the same kernel body (same bits, same order of accumulation as the fused pass in two steps).
 // VT = the lane value: double or float (one cell per lane), or F2 (two fp32 cells per lane, packed arithmetic: cell_ops.h);
 // TF = its scalar type (metrics, coefficients, the arrays in memory); CW = cells per lane, a wave spans 64*CW cells of a row.
-template<class VT, int NJ, bool HAS_S, int PB, bool ADV = true, bool DIF = true>
+// HX = cells the u, v, w, s tile starts west of the block's first cell: 3 (the stencil's reach) or 4 where that makes the tile's
+// origin a whole 16-byte piece (e.g. 16 ghost cells in x: Grid::set_minimum_ghost_cells, src/grid.cxx:435-439)
+template<class VT, int NJ, bool HAS_S, int PB, bool ADV = true, bool DIF = true, int HX = 3>
 __global__ void __launch_bounds__(64*NJ, (sizeof(VT) == 4 ? MHH_MARCH_OCC_F32 : MHH_MARCH_OCC))
 rhs25_march_kernel(const GridDev<typename lane_of<VT>::scalar> g, const MarchFields<typename lane_of<VT>::scalar> f, const MarchTiling mt)
 {
@@ -136,7 +138,7 @@ rhs25_march_kernel(const GridDev<typename lane_of<VT>::scalar> g, const MarchFie
     static_assert(PB == 16 || PB == 4, "piece size of the LDS-DMA copies");
     constexpr int VEC = 16 / (int)sizeof(TF);                       // elements per 16-byte DMA piece
     constexpr int AL = (PB == 16) ? VEC : 1;                        // granularity of tile widths / origins in elements
-    constexpr int TI = ((64*CW + 6 + AL-1)/AL)*AL;                  // u,v,w,s tile: x from i0-3
+    constexpr int TI = ((64*CW + HX + 3 + AL-1)/AL)*AL;             // u,v,w,s tile: x from i0-HX
     constexpr int EX = (PB == 16) ? VEC : 1;                        // evisc tile: x from i0-EX (aligned for 16-byte DMA)
     constexpr int TE = ((64*CW + EX + 1 + AL-1)/AL)*AL;
     constexpr int TJ = NJ + 6, TJE = NJ + 2, NT = 64*NJ;
@@ -160,7 +162,7 @@ rhs25_march_kernel(const GridDev<typename lane_of<VT>::scalar> g, const MarchFie
     const int ci = (i + SEC < g.iend) ? i : g.iend-1-SEC, cj = (j < mt.jlim) ? j : mt.jlim-1;   // clamped column for the window loads
     const int col = ci + cj*jj;
     const int ij = col;
-    const int l = (ty+3)*TI + (tx+3), le = (ty+1)*TE + (tx+EX);
+    const int l = (ty+3)*TI + (tx+HX), le = (ty+1)*TE + (tx+EX);
     // a plane in LDS as seen from the lane's cell: [o] = the lane value o cells away (CW = 2: the lane's two cells, one ds_read2_b32)
     struct LV
     {
@@ -210,7 +212,7 @@ rhs25_march_kernel(const GridDev<typename lane_of<VT>::scalar> g, const MarchFie
     {
         const int e = (tid + n*NT < NP) ? tid + n*NT : NP-1;
         const int tj = e / PPR, tw = (e - tj*PPR)*PW;
-        int gw = (i0 - 3)*EW + tw, gj = j0 - 3 + tj;
+        int gw = (i0 - HX)*EW + tw, gj = j0 - 3 + tj;
         if (gw + PW > g.icells*EW) gw = g.icells*EW - PW;
         if (gj >= g.jcells) gj = g.jcells - 1;
         off[n] = (unsigned)(gw + gj*jj*EW) * 4u;
@@ -647,7 +649,11 @@ int march_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* 
 #define MHH_LAUNCH_MARCH(PBV, A, D) do { \
         if (has_s) hipLaunchKernelGGL((rhs25_march_kernel<VT, NJ, true, PBV, A, D>),  dim3(nblocks), dim3(64, NJ), 0, st, gd, mf, t); \
         else       hipLaunchKernelGGL((rhs25_march_kernel<VT, NJ, false, PBV, A, D>), dim3(nblocks), dim3(64, NJ), 0, st, gd, mf, t); } while (0)
-    if (mode == 0)      { if (pb == 16) MHH_LAUNCH_MARCH(16, true, true);  else MHH_LAUNCH_MARCH(4, true, true); }
+    // tile origin on a 16-byte piece where three cells west of the first cell is not one (istart = 16: rows of whole cache lines)
+    const char* ehx = getenv("MHH_MARCH_HX");
+    const bool hx4 = mode == 0 && has_s && pb == 16 && (g->istart - 3) % VEC != 0 && (g->istart - 4) % VEC == 0 && g->istart >= 4 && !(ehx && !strcmp(ehx, "3"));
+    if (hx4) hipLaunchKernelGGL((rhs25_march_kernel<VT, NJ, true, 16, true, true, 4>), dim3(nblocks), dim3(64, NJ), 0, st, gd, mf, t);
+    else if (mode == 0) { if (pb == 16) MHH_LAUNCH_MARCH(16, true, true);  else MHH_LAUNCH_MARCH(4, true, true); }
     else if (mode == 1) { if (pb == 16) MHH_LAUNCH_MARCH(16, true, false); else MHH_LAUNCH_MARCH(4, true, false); }
     else                { if (pb == 16) MHH_LAUNCH_MARCH(16, false, true); else MHH_LAUNCH_MARCH(4, false, true); }
 #undef MHH_LAUNCH_MARCH

@@ -29,11 +29,11 @@ constexpr int MAXF = 8;
 template<class TF> struct FieldList { TF* f[MAXF]; };
 
 template<class TF>
-__global__ void __launch_bounds__(256) cyclic_x_kernel(FieldList<TF> fl, int igc, int iend, int istart, int icells, int nrows)
+__global__ void __launch_bounds__(256) cyclic_x_kernel(FieldList<TF> fl, int igc, int iend, int istart, int icells, int nrows, int tpr)
 {
-    // a row = one (j,k) line; each thread copies one west and one east ghost cell
-    const int t = threadIdx.x % 8;                // igc <= 8
-    const int row = blockIdx.x * (256/8) + threadIdx.x / 8;
+    // a row = one (j,k) line; each thread copies one west and one east ghost cell; tpr = threads per row (8, 16 or 32 >= igc)
+    const int t = threadIdx.x % tpr;
+    const int row = blockIdx.x * (256/tpr) + threadIdx.x / tpr;
     if (t >= igc || row >= nrows) return;
     TF* __restrict__ a = fl.f[blockIdx.y] + (size_t)row * icells;
     a[t] = a[iend - igc + t];
@@ -68,7 +68,8 @@ template<class TF>
 static int cyclic_launch(const mhh_grid* g, void* const* data, int nf, int edge, int kcells, int kstart, int kend, hipStream_t st)
 {
     MHH_REQUIRE(nf >= 1 && nf <= MAXF, "1..8 fields per call");
-    MHH_REQUIRE(g->igc <= 8 && g->jgc <= 8, "ghost width <= 8");
+    MHH_REQUIRE(g->igc <= 32 && g->jgc <= 32, "ghost width <= 32");
+    const int tpr = (g->igc <= 8) ? 8 : (g->igc <= 16 ? 16 : 32), rpb = 256 / tpr;
     MHH_REQUIRE(g->imax >= g->igc && (g->jtot == 1 || g->jmax >= g->jgc), "the interior must be at least as wide as the ghost zone it fills (src/grid.cxx:420)");
     FieldList<TF> fl;
     for (int n=0; n<MAXF; ++n) fl.f[n] = mp<TF>(data[n < nf ? n : 0]);
@@ -76,7 +77,7 @@ static int cyclic_launch(const mhh_grid* g, void* const* data, int nf, int edge,
     if (edge == MHH_EDGE_EW || edge == MHH_EDGE_BOTH)
     {
         const int nrows = g->jcells * kcells;
-        hipLaunchKernelGGL(cyclic_x_kernel<TF>, dim3((nrows + 31)/32, nf), dim3(256), 0, st, fl, g->igc, g->iend, g->istart, g->icells, nrows);
+        hipLaunchKernelGGL(cyclic_x_kernel<TF>, dim3((nrows + rpb-1)/rpb, nf), dim3(256), 0, st, fl, g->igc, g->iend, g->istart, g->icells, nrows, tpr);
         MHH_LAUNCH_CHECK();
     }
     if (edge == MHH_EDGE_NS || edge == MHH_EDGE_BOTH)

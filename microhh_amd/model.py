@@ -56,7 +56,7 @@ class HotPath:
     """Device-resident fields of ONE rank + the operator calls of one sub-step."""
 
     def __init__(self, case, itot, jtot, ktot, dtype=np.float64, device="cuda:0", seed=666, dt=1.0,
-                 lib=None, npy=1, rank=0, group=None, global_init=None, force_slab=False, slim_halos=True, overlap=None, pres_chunks=None):
+                 lib=None, npy=1, rank=0, group=None, global_init=None, force_slab=False, slim_halos=True, overlap=None, pres_chunks=None, igc=None):
         import torch
         self.torch = torch
         self.lib = lib if lib is not None else capi.lib()
@@ -73,9 +73,11 @@ class HotPath:
         # MHH_OVERLAP=1 / overlap=True force it, also on one rank with force_slab): the exchange it hides (25.5 MB each way per
         # rank at 512^3 / 8) costs more on the wire than the ~0.2 ms of smaller edge launches the split adds.
         env = os.environ.get("MHH_OVERLAP")
-        if overlap is None:
-            overlap = (npy > 1) if env is None else (env == "1")
-        self.overlap = bool(overlap) or env == "1"
+        if env in ("0", "1"):                        # the environment wins over the argument, both ways
+            overlap = (env == "1")
+        elif overlap is None:
+            overlap = npy > 1
+        self.overlap = bool(overlap)
         self._comm_stream = None
         self.device = torch.device(device)
         self.on_gpu = self.device.type == "cuda"
@@ -99,7 +101,10 @@ class HotPath:
         if self.slab and cfg["pres"] != 2:
             raise ValueError("slab decomposition implements pres_2 (BASELINE.json multi-GPU configs use pres_2)")
         z = moser_z(ktot, cfg["size"][2]) if case == "moser600" else None
-        self.grid = g = Grid(itot, jtot, ktot, *cfg["size"], order=cfg["order"], igc=cfg["gc"][0], jgc=cfg["gc"][1], kgc=cfg["gc"][2],
+        # igc: ghost cells in x beyond what the schemes need -- what the reference's grid produces when an operator calls
+        # Grid::set_minimum_ghost_cells (src/grid.cxx:435-439; src/advec_2i5.cxx:42-45 uses it). igc = 16 with itot = 512 makes
+        # rows of 544 cells = 34 whole 128-byte lines with istart on a line (fp64).
+        self.grid = g = Grid(itot, jtot, ktot, *cfg["size"], order=cfg["order"], igc=max(cfg["gc"][0], igc or 0), jgc=cfg["gc"][1], kgc=cfg["gc"][2],
                              z=z, dtype=dtype, npy=npy, mpicoordy=rank)
         self.G = g.device_struct(self.device) if self.on_gpu else g.host_struct()
         self.td = td = torch.float64 if np.dtype(dtype) == np.float64 else torch.float32
@@ -179,6 +184,7 @@ class HotPath:
             if pres_chunks is None:
                 env = os.environ.get("MHH_PRES_CHUNKS")
                 pres_chunks = int(env) if env else (4 if npy > 1 else 1)
+            pres_chunks = max(1, int(pres_chunks))
             while pres_chunks > 1 and (ktot % pres_chunks or not self.slim):
                 pres_chunks -= 1
             self.pres_chunks = pres_chunks

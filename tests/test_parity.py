@@ -275,6 +275,40 @@ def test_operator_exec_and_fused_rhs_bitexact(be, adv, dif, sm, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_fused_rhs_and_viscosity_with_sixteen_ghost_cells_in_x(be, dtype):
+    """A grid whose operators asked for more ghost cells (Grid::set_minimum_ghost_cells, src/grid.cxx:435-439, as
+    src/advec_2i5.cxx:42-45 does): igc = 16 makes rows of 512 + 32 cells whole 128-byte lines with istart on a line. Same
+    operators, same bits; the marching kernels take their tile origins from istart."""
+    adv, dif, sm = cm.ADVEC_2I5, cm.DIFF_SMAG2, 1
+    O = cm.oracle()
+    for g in (cm.grid_2nd(70, 9, 10, gc=(16, 3, 1), dtype=dtype), cm.grid_2nd(128, 6, 8, gc=(16, 3, 1), dtype=dtype), cm.grid_2nd(16, 5, 8, gc=(4, 3, 1), dtype=dtype)):
+        for rho in ("one", "random"):
+            c = cm.Case(g, nscalars=1, rho=rho, periodic=True)
+            want = _oracle_rhs(c, adv, dif, sm)
+            p = capi.MhhDiffParams(); p.cs = 0.23; p.tPr = 1./3.; p.surface_model = sm
+            d = B.DevCase(be, c); f = d.fields()
+            B.ok(be, be.lib.mhh_rhs_exec(d.G, adv, dif, C.byref(f), C.byref(p), be.stream))
+            got = (be.host(d.ut), be.host(d.vt), be.host(d.wt), [be.host(x) for x in d.st])
+            for a, b, nm in zip(got[:3], want[:3], "uvw"):
+                assert same(a, b), ("fused", nm, g.shape3, rho, cm.ulp_diff(a, b))
+            assert same(got[3][0], want[3][0]), ("fused s", g.shape3, rho)
+        # exec_viscosity on the same layout: marching form == cell form is tested elsewhere; here against the oracle
+        c = cm.Case(g, periodic=True); Gh = g.host_struct()
+        thref = np.full(g.kcells, 300., dtype=dtype)
+        want = np.zeros(g.shape3, dtype=dtype); n2 = np.zeros(g.shape3, dtype=dtype)
+        O.orc_smag2_strain2(Gh, sm, ptr(want), ptr(c.u), ptr(c.v), ptr(c.w), ptr(c.dudz), ptr(c.dvdz))
+        O.orc_calc_N2(Gh, ptr(n2), ptr(c.s[0]), ptr(thref), dbl(9.81))
+        O.orc_smag2_evisc(Gh, sm, ptr(want), ptr(n2), ptr(c.dbdz), ptr(c.z0m), dbl(0.23), dbl(1./3.))
+        O.orc_boundary_cyclic(Gh, ptr(want), cm.EDGE_BOTH)
+        d = B.DevCase(be, c); f = d.fields()
+        p = capi.MhhDiffParams(); p.cs = 0.23; p.tPr = 1./3.; p.surface_model = sm; p.grav = 9.81
+        dth = be.arr(thref); p.thref = be.ptr(dth).value
+        ml = B.mlen0(be, g, 0.23); p.mlen0 = be.ptr(ml).value
+        B.ok(be, be.lib.mhh_diff_exec_viscosity(d.G, dif, C.byref(f), C.byref(p), be.stream))
+        assert cm.ulp_diff(be.host(d.evisc)[g.kstart:g.kend], want[g.kstart:g.kend]) <= 8, g.shape3
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("limited", [(0,), (1,), (0, 1)])
 def test_fused_rhs_with_fluxlimit_list(be, limited, dtype):
     """advec.fluxlimit_list (src/advec_2i5.cxx:39,921): the listed scalars take the Koren-limited scheme inside
