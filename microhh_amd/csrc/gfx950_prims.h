@@ -129,6 +129,25 @@ template<class T> __device__ __forceinline__ T uniform_load(const T* table, int 
     typedef const T __attribute__((address_space(4)))* const_ptr;
     return ((const_ptr)(table))[idx];
 }
+// Eight consecutive wave-uniform elements in one scalar load (s_load_dwordx16 / x8)
+template<class T> struct alignas(16) Uniform8 { T v[8]; };
+template<class T> __device__ __forceinline__ Uniform8<T> uniform_load8(const T* table)
+{
+    typedef T vec8 __attribute__((ext_vector_type(8)));
+    typedef const vec8 __attribute__((address_space(4)))* const_ptr;
+    const vec8 x = *(const_ptr)(table);
+    Uniform8<T> r;
+#pragma unroll
+    for (int n=0; n<8; ++n) r.v[n] = x[n];
+    return r;
+}
+// The kernel's FIRST argument as memory: the kernel-argument segment is constant memory behind the scalar cache, so a kernel can
+// re-read a by-value argument with s_load where it needs it instead of holding it in registers from its first instruction on.
+// (Taking the address of the parameter itself would make the compiler copy it to scratch.)
+template<class T> __device__ __forceinline__ const T* first_kernarg(const T&)
+{
+    return (const T*)__builtin_amdgcn_kernarg_segment_ptr();
+}
 // Loads / stores of data touched once per kernel (the tendencies of the marching kernels): the non-temporal hint lets them
 // stream past L2 instead of evicting the planes that neighbouring tiles re-read.
 template<class T> __device__ __forceinline__ T stream_load(const T* q) { return __builtin_nontemporal_load(q); }
@@ -169,6 +188,9 @@ template<class T> __device__ __forceinline__ void gstore_stream(T* uniform_base,
 }
 // Opaque re-definition of a per-lane value (no instruction): what is computed from it cannot be hoisted above this point.
 __device__ __forceinline__ void keep_vgpr(unsigned& x) { asm volatile("" : "+v"(x)); }
+// The same for a value of any register type: it lives in vector registers from here on (e.g. a scalar that several VOP3
+// instructions need beside another scalar operand: one v_mov here instead of one per use)
+template<class T> __device__ __forceinline__ void pin_vgpr(T& x) { asm volatile("" : "+v"(x)); }
 // Orders the LDS traffic of ONE wave: what its lanes wrote before this point is what its lanes read after it. The LDS serves a
 // wave's instructions in order, so no s_barrier is involved -- the fence only keeps the compiler from moving accesses across.
 __device__ __forceinline__ void wave_sync()

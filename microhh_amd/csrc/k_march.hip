@@ -75,24 +75,58 @@ template<class TF> __device__ __forceinline__ void shift6(TF (&w)[6], TF nw)
     w[0] = w[1]; w[1] = w[2]; w[2] = w[3]; w[3] = w[4]; w[4] = w[5]; w[5] = nw;
 }
 
+// The uniform coefficients of a level, as the kernel's FIRST argument: the kernel reads them from the kernel-argument segment with
+// scalar loads inside every level (two groups of eight: what the u, v, w sections use / what the scalar's section uses) instead of
+// holding all fourteen (28 scalar registers in fp64) across the whole kernel. With them live throughout, the register allocator
+// spilled scalars to vector-register lanes and restored them with v_readlane -- a VECTOR instruction, the one issue resource this
+// kernel is short of (36-65 per level and wave, PMC: kernel time follows the VALU count; profiles/r3_march_kernel.md).
+template<class TF> struct alignas(16) MarchMetrics
+{
+    TF dxih, dyih;                               // 0.5 * TF(1.)/dx : advection of u, v, w (the 1/2 of the advecting-velocity mean folded in)
+    TF dxd, dyd, dxd2, dyd2;                     // TF(1./dx) and twice that: diffusion
+    TF visc, quarter;                            // quarter = 0.25 (see quarter_plus)
+    TF dxi, dyi;                                 // TF(1.)/dx       : advection of the scalar
+    TF dxidxi, dyidyi;                           // TF(1./(dx*dx)): diffusion of the scalar
+    TF svisc;
+    TF tPr2, rtPr2;                              // 2 tPr and RN(1 / (2 tPr)): 0.5*(a+b)/tPr is div_known(a+b, tPr2, rtPr2)
+    TF pad1;
+};
+
+// 0.25*x + c in one instruction: the product with a power of two is exact (no underflow: eddy viscosities are zero or far above
+// 2^-1020), so the fused multiply-add rounds once, exactly where the reference's addition rounds -- the same bits, one vector
+// instruction less per four-point average of the eddy viscosity (ten per cell and level)
+// Scheduling fences between the sections of a level (MHH_MARCH_FENCE=0 drops them): without them the scheduler hoists LDS reads
+// across sections, shares eight operations between sections, and needs a register more than the 255 there are -- one scratch
+// reload per level, i.e. a vmcnt(0) wait in the middle of the copies in flight: 5.06 against 4.74 ms (profiles/r3_march_kernel.md)
+#ifndef MHH_MARCH_FENCE
+#define MHH_MARCH_FENCE 1
+#endif
+__device__ __forceinline__ void mfence() { if constexpr (MHH_MARCH_FENCE != 0) sched_fence(); }
+// (0.25 arrives as a scalar operand and c in a vector register: a VOP3 instruction takes one scalar register operand and no 32-bit
+// literal on gfx9, and 0.25 is not an inline constant -- with both as scalars the compiler emitted v_mov + v_fmac, no saving)
+template<class VT, class TF> __device__ __forceinline__ VT quarter_plus(VT x, TF quarter, VT c) { return tfma(x, VT(quarter), c); }
+
+
 template<class TF> struct MarchFields
 {
     // hot: every level of the interior loop uses these
     const TF* __restrict__ u; const TF* __restrict__ v; const TF* __restrict__ w; const TF* __restrict__ s; const TF* __restrict__ ev;
     TF* __restrict__ ut; TF* __restrict__ vt; TF* __restrict__ wt; TF* __restrict__ st;
-    TF dxih, dyih;                               // 0.5 * TF(1.)/dx : advection of u, v, w (the 1/2 of the advecting-velocity mean folded in)
-    TF dxi, dyi;                                 // TF(1.)/dx       : advection of the scalar
-    TF dxd, dyd, dxd2, dyd2;                     // TF(1./dx) and twice that: diffusion
-    TF dxidxi, dyidyi;                           // TF(1./(dx*dx)): diffusion of the scalar
-    TF visc, svisc;
-    TF tPr2, rtPr2;                              // 2 tPr and RN(1 / (2 tPr)): 0.5*(a+b)/tPr is div_known(a+b, tPr2, rtPr2)
     // cold: walls, surface model, anelastic base state, folded buoyancy
     const TF* __restrict__ rhoref; const TF* __restrict__ rhorefh;
     const TF* __restrict__ ufb; const TF* __restrict__ uft; const TF* __restrict__ vfb; const TF* __restrict__ vft;
     const TF* __restrict__ sfb; const TF* __restrict__ sft;
     const TF* __restrict__ threfh; TF grav;      // folded dry buoyancy of the scalar (threfh == nullptr: off)
     int sm;
+#ifdef MHH_MARCH_STAMP      // probe builds: per-wave cycle sums of the phases of a level (scripts/experiments/march_stamps.py)
+    unsigned long long* dbg;
+#endif
 };
+#ifdef MHH_MARCH_STAMP
+#define MHH_STAMP(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); stamp_acc[i] += t_ - stamp_last; stamp_last = t_; } while (0)
+#else
+#define MHH_STAMP(i) do {} while (0)
+#endif
 
 // x * 2^E for a wave-uniform, normal, non-zero x (a grid metric): an integer add on the exponent field, which stays on the
 // scalar ALU -- gfx950 has no scalar fp64 multiply, and a vector one would park the uniform result in vector registers.
@@ -127,7 +161,7 @@ template<int E> __device__ __forceinline__ float scale2(float x)
 // origin a whole 16-byte piece (e.g. 16 ghost cells in x: Grid::set_minimum_ghost_cells, src/grid.cxx:435-439)
 template<class VT, int NJ, bool HAS_S, int PB, bool ADV = true, bool DIF = true, int HX = 3>
 __global__ void __launch_bounds__(64*NJ, (sizeof(VT) == 4 ? MHH_MARCH_OCC_F32 : MHH_MARCH_OCC))
-rhs25_march_kernel(const GridDev<typename lane_of<VT>::scalar> g, const MarchFields<typename lane_of<VT>::scalar> f, const MarchTiling mt)
+rhs25_march_kernel(const MarchMetrics<typename lane_of<VT>::scalar> mm, const GridDev<typename lane_of<VT>::scalar> g, const MarchFields<typename lane_of<VT>::scalar> f, const MarchTiling mt)
 {
     using TF = typename lane_of<VT>::scalar;
     constexpr int CW = lane_of<VT>::cells;
@@ -142,7 +176,15 @@ rhs25_march_kernel(const GridDev<typename lane_of<VT>::scalar> g, const MarchFie
     constexpr int EX = (PB == 16) ? VEC : 1;                        // evisc tile: x from i0-EX (aligned for 16-byte DMA)
     constexpr int TE = ((64*CW + EX + 1 + AL-1)/AL)*AL;
     constexpr int TJ = NJ + 6, TJE = NJ + 2, NT = 64*NJ;
-    constexpr int NTILE = TI*TJ, NETILE = TE*TJE;
+    // A tile slot in LDS is a whole number of wave sweeps (64 pieces of PB bytes): the last sweep of a tile copies (clamped, valid)
+    // duplicates into the slot's padding instead of running under a lane mask -- per tile and level that mask was two v_readlane of
+    // a spilled exec mask, four scalar instructions and a branch
+#ifndef MHH_MARCH_PAD
+#define MHH_MARCH_PAD 1
+#endif
+    constexpr bool PAD = (MHH_MARCH_PAD != 0);
+    constexpr int NTILE = PAD ? ((TI*TJ*(int)sizeof(TF) + 64*PB - 1) / (64*PB)) * (64*PB) / (int)sizeof(TF) : TI*TJ;
+    constexpr int NETILE = PAD ? ((TE*TJE*(int)sizeof(TF) + 64*PB - 1) / (64*PB)) * (64*PB) / (int)sizeof(TF) : TE*TJE;
     // LDS rings, one slot deeper than what a level reads so that the copy of the next plane runs under the whole compute
     // phase: u, v, s: level k; w: k and k+1; evisc: k-1..k+1. One array, so that every plane is a compile-time offset from
     // one base (ds_read immediates; the LDS-DMA destination is base + constant).
@@ -183,19 +225,16 @@ rhs25_march_kernel(const GridDev<typename lane_of<VT>::scalar> g, const MarchFie
     // the 2- and 3-deep rings are compile-time constants (12 is a multiple of every ring depth; planes from kb-2 on are
     // copied: p - kg0 >= -5)
     const int kg0 = (kf0 - kb <= 3) ? kf0 : kb;
-    auto slot = [&](int p, int r) { return (p - kg0 + 12) % r; };
+    auto slot = [&](int p, int r) { const unsigned q = (unsigned)(p - kg0 + 12); return (int)((r & (r-1)) == 0 ? (q & (unsigned)(r-1)) : q % (unsigned)r); };
 
     // ---- wave-uniform values of the interior loop, each pinned in scalar registers of its own. Without this the compiler
     // keeps the kernel-argument structs as the 16-dword tuples its merged s_loads produced, spills them whole and restores
     // all sixteen dwords (v_readlane: a VECTOR instruction each) to use one pointer -- ~190 of them per level. ------------
     const size_t kk8 = sgpr((size_t)kk * sizeof(TF));              // bytes per plane
     auto adv = [&](const TF* q, int n) -> const TF* { return reinterpret_cast<const TF*>(reinterpret_cast<const char*>(q) + n*kk8); };
-    const TF dxih = sgpr(f.dxih), dyih = sgpr(f.dyih), dxi = sgpr(f.dxi), dyi = sgpr(f.dyi);
-    const TF dxd = sgpr(f.dxd), dyd = sgpr(f.dyd), dxd2 = sgpr(f.dxd2), dyd2 = sgpr(f.dyd2);
-    const TF dxidxi = sgpr(f.dxidxi), dyidyi = sgpr(f.dyidyi);
-    const TF visc = sgpr(f.visc), svisc = sgpr(f.svisc), tPr2 = sgpr(f.tPr2), rtPr2 = sgpr(f.rtPr2);
+    // the uniform coefficients: read per level from the kernel-argument segment (see MarchMetrics)
+    const TF* const kmm = first_kernarg(reinterpret_cast<const TF&>(mm));
     const TF* __restrict__ tdzi = sgpr(g.dzi); const TF* __restrict__ tdzhi = sgpr(g.dzhi);
-    auto div_tpr = [&](VT x) -> VT { return div_known(x, tPr2, rtPr2); };     // 0.5*x / tPr
 
     // ---- tile movers. A tile is walked in pieces of PW 32-bit words: e = tid + n*NT; piece -> (row, first word) --------
     constexpr int EW = (int)sizeof(TF) / 4;                           // words per element
@@ -248,17 +287,20 @@ rhs25_march_kernel(const GridDev<typename lane_of<VT>::scalar> g, const MarchFie
         }
     };
     // pl = the plane to copy (a wave-uniform pointer inside the array)
+    // a wave takes part in sweep n if its first piece lies inside the tile: a wave-uniform (scalar) condition
+    const int wave_p0 = (int)uniform_u32((unsigned)wave_e0);
+    const int wave_ph = (int)uniform_u32((unsigned)ty) & 3;       // this wave's number in the block (a scalar)
     auto dma_tile = [&](const TF* __restrict__ pl, int lo)
     {
 #pragma unroll
         for (int n=0; n<NLD; ++n)
-            if ((n+1)*NT <= NP || tid + n*NT < NP) dma_piece(pl, off[n], lo, n);
+            if ((n+1)*NT <= NP || (PAD ? wave_p0 + n*NT < NP : tid + n*NT < NP)) dma_piece(pl, off[n], lo, n);
     };
     auto dma_etile = [&](const TF* __restrict__ pl, int lo)
     {
 #pragma unroll
         for (int n=0; n<NLDE; ++n)
-            if ((n+1)*NT <= NPE || tid + n*NT < NPE) dma_piece(pl, offe[n], lo, n);
+            if ((n+1)*NT <= NPE || (PAD ? wave_p0 + n*NT < NPE : tid + n*NT < NPE)) dma_piece(pl, offe[n], lo, n);
     };
     const int kmaxp = g.kcells - 1;                                   // planes are clamped into [0, kcells-1]: values read from a
     auto plane = [&](const TF* __restrict__ fld, int kp) -> const TF*   // clamped plane are never used by an updated level
@@ -281,9 +323,7 @@ rhs25_march_kernel(const GridDev<typename lane_of<VT>::scalar> g, const MarchFie
     auto tld = [](const TF* base, unsigned bo) -> VT { if constexpr (CW == 1) return gload(base, bo); else return VT(gload(base, bo), gload(base, bo + 4u*SEC)); };
     auto tst = [](TF* base, unsigned bo, VT v) { if constexpr (CW == 1) gstore(base, bo, v); else { gstore(base, bo, v.lo()); gstore(base, bo + 4u*SEC, v.hi()); } };
 #endif
-    unsigned bo0 = (unsigned)col * (unsigned)sizeof(TF);              // this column in a plane, one / two / three planes up
-    unsigned bo1 = (unsigned)(col + kk) * (unsigned)sizeof(TF), bo2 = (unsigned)(col + 2*kk) * (unsigned)sizeof(TF);
-    unsigned bo3 = (unsigned)(col + 3*kk) * (unsigned)sizeof(TF);
+    unsigned bo0 = (unsigned)col * (unsigned)sizeof(TF);              // this column in the plane of the running level (advances by a plane per level)
 
     // ---- prologue: the planes level ks reads, windows centred on ks ----------------------------------------------------
     const int ks = kb - 1;                 // warm-up level: only top-face quantities are formed there
@@ -300,10 +340,15 @@ rhs25_march_kernel(const GridDev<typename lane_of<VT>::scalar> g, const MarchFie
     }
     // running plane pointers (wave-uniform): at level k, pu / pv / ps point at plane k+1, pw / pe at plane k+2 (the planes
     // to copy; the window values of level k+4 are three / two planes further up), the tendencies' at plane k
-    const TF* pu = sgpr(f.u + (size_t)(ks+1)*kk); const TF* pv = sgpr(f.v + (size_t)(ks+1)*kk); const TF* pw = sgpr(f.w + (size_t)(ks+2)*kk);
-    const TF* ps = HAS_S ? sgpr(f.s + (size_t)(ks+1)*kk) : nullptr; const TF* pe = DIF ? sgpr(f.ev + (size_t)(ks+2)*kk) : nullptr;
-    TF* put = sgpr(f.ut + (long long)ks*kk); TF* pvt = sgpr(f.vt + (long long)ks*kk); TF* pwt = sgpr(f.wt + (long long)ks*kk);
-    TF* pst = HAS_S ? sgpr(f.st + (long long)ks*kk) : nullptr;
+    // Plane BASES of the chunk, constant through the kernel; the level enters through the lanes' byte offsets, which advance by one
+    // plane per level (seven 32-bit vector adds). Running scalar POINTERS were rewritten by the loop optimiser into spilled bases
+    // plus m x stride and cost 15 v_readlane and ~40 scalar instructions per level. (32-bit offsets: the host keeps
+    // (kc + 8) planes below 4 GB, march_launch.)
+    const TF* const pu = sgpr(f.u + (size_t)(ks+1)*kk); const TF* const pv = sgpr(f.v + (size_t)(ks+1)*kk); const TF* const pw = sgpr(f.w + (size_t)(ks+2)*kk);
+    const TF* const ps = HAS_S ? sgpr(f.s + (size_t)(ks+1)*kk) : nullptr; const TF* const pe = DIF ? sgpr(f.ev + (size_t)(ks+2)*kk) : nullptr;
+    TF* const put = sgpr(f.ut + (long long)ks*kk); TF* const pvt = sgpr(f.vt + (long long)ks*kk); TF* const pwt = sgpr(f.wt + (long long)ks*kk);
+    TF* const pst = HAS_S ? sgpr(f.st + (long long)ks*kk) : nullptr;
+    const unsigned kk8w = sgpr((unsigned)kk8);                     // bytes per plane as a 32-bit scalar
     wait_vmem();
     __syncthreads();
 
@@ -328,6 +373,9 @@ rhs25_march_kernel(const GridDev<typename lane_of<VT>::scalar> g, const MarchFie
     VT dss = zero; bool dsp = false;       // deferred scalar tendency of the level below
     VT tpu = zero, tpv = zero, tpw = zero, tps = zero;
 
+#ifdef MHH_MARCH_STAMP
+    unsigned long long stamp_acc[5] = {0, 0, 0, 0, 0}, stamp_last = __builtin_readcyclecounter();
+#endif
     // One level. FAST = an interior level of an updating iteration: every vertical face is 6th/5th order, no wall or
     // surface-flux branch applies -- the face orders and the wall predicates become constants and their dispatch
     // (a third of the loop's scalar / control instructions) disappears. Same arithmetic either way.
@@ -341,36 +389,68 @@ rhs25_march_kernel(const GridDev<typename lane_of<VT>::scalar> g, const MarchFie
         auto R = [](TF r, VT x) -> VT { return RHO1 ? x : r*x; };
         // ring slot of plane k+d: inside a rotated group k - kg0 = ROT (mod 6), a constant for the rings whose depth divides 6
         auto sl = [&](int d, int r) { return (ROT >= 0 && 6 % r == 0) ? (ROT + d + 12) % r : slot(k + d, r); };
-        // the lane offsets of the column accesses, re-defined (by nothing) in every level: as loop invariants their zero
-        // extension to 64 bits is hoisted, and the accesses then take 64-bit vector addresses (v_lshl_add_u64 each, two
-        // registers per offset) instead of the scalar-base + 32-bit-offset form
-        keep_vgpr(bo0); keep_vgpr(bo1); keep_vgpr(bo2); keep_vgpr(bo3);
-        // ---- start moving the next level's planes: k+1 of u, v, s; k+2 of w, evisc; window value k+4 -------------------
-        const bool more = (k + 1 < ke);
-#ifndef MHH_EXP_NOMEM
-        if (more)
+        const TF* const mq = sgpr(kmm);                          // opaque per level: the loads stay inside the level
+        const Uniform8<TF> mg0 = uniform_load8(mq);
+        const TF dxih = mg0.v[0], dyih = mg0.v[1], dxd = mg0.v[2], dyd = mg0.v[3], dxd2 = mg0.v[4], dyd2 = mg0.v[5], visc = mg0.v[6], quarter = mg0.v[7];
+        VT viscv = VT(visc); if constexpr (CW == 1) pin_vgpr(viscv); else pin_vgpr(viscv.v);                    // the viscosity once per level in a vector register (quarter_plus)
+        MHH_STAMP(4);                                             // (loop control, window rotation: since the last barrier)
+        // ---- moving the next level's planes: k+1 of u, v, s; k+2 of w, evisc; window value k+4 ---------------------------
+        // The four waves of a block leave the barrier together, and a wave issues in order: with all copies at the top of the
+        // level every wave sat out the block's whole burst of vector-memory instructions in the address unit's queue before its
+        // first arithmetic (cycle stamps, profiles/r3_march_kernel.md: ~1500 of a level's ~8500 wave cycles). The copies are
+        // therefore issued in GROUPS between the sections of the level (MHH_MARCH_SPREAD: 0 = all at the top, as in round 2).
+        // (the test `k + 1 < ke` is spelled out where it is used: as a bool carried between basic blocks it became a lane mask rebuilt
+        //  with two vector instructions per use)
+        // k + 1 < ke: k+2 <= ke <= kend lies inside the array
+        auto copy_group = [&](int grp) __attribute__((always_inline))
         {
-            // more: k+2 <= ke <= kend lies inside the array
-            dma_tile(pu, OU + sl(1, RU)*NTILE); dma_tile(pv, OV + sl(1, RU)*NTILE); dma_tile(pw, OW + sl(2, RW)*NTILE);
-            if constexpr (DIF) dma_etile(pe, OE + sl(2, RE)*NETILE);
-            if constexpr (HAS_S) dma_tile(ps, OS + sl(1, RS)*NTILE);
-        }
+#ifndef MHH_EXP_NOMEM
+            if (k + 1 < ke)
+            {
+                if (grp == 0) { dma_tile(pu, OU + sl(1, RU)*NTILE); dma_tile(pv, OV + sl(1, RU)*NTILE); }
+                if (grp == 1) { dma_tile(pw, OW + sl(2, RW)*NTILE); if constexpr (DIF) dma_etile(pe, OE + sl(2, RE)*NETILE); }
+                if (grp == 2) { if constexpr (HAS_S) dma_tile(ps, OS + sl(1, RS)*NTILE); }
+            }
 #endif
+        };
+        // where group g is issued: position 0 = top of the level, 1 = after the advective top faces, 2 = after the diffusive top
+        // faces (all ahead of the masked update of the tendencies: every lane issues its pieces)
+#ifndef MHH_MARCH_SPREAD
+#define MHH_MARCH_SPREAD 1
+#endif
+        constexpr int SPREAD = (sizeof(VT) == 8) ? MHH_MARCH_SPREAD : 0;
+        auto copies_at = [&](int pos) __attribute__((always_inline))
+        {
+            constexpr int where[3][3] = { {0, 0, 0}, {0, 1, 2}, {1, 2, 2} };
+            bool any = false;
+            for (int g_ = 0; g_ < 3; ++g_) if (where[SPREAD][g_] == pos) any = true;
+            if (!any) return;
+            if (pos > 0) mfence();
+            for (int g_ = 0; g_ < 3; ++g_) if (where[SPREAD][g_] == pos) copy_group(g_);
+            mfence();
+        };
+        copies_at(0);
         // window values of level k+4, read unconditionally (no select, no copy): past the top of the array the plane pointer
         // steps back onto the last plane -- such values only enter faces above the top wall, which are never formed
-        const int over = (k + 4 > kmaxp) ? kmaxp - (k + 4) : 0;    // <= 0
+        // (an interior level has k + 4 <= kend <= kcells - 1: nothing to step back, and no 64-bit scalar multiply per level)
+        const int over = FAST ? 0 : ((k + 4 > kmaxp) ? kmaxp - (k + 4) : 0);    // <= 0
 #if !defined(MHH_EXP_NOMEM) && !defined(MHH_EXP_NOCOL)
-        const VT nu = gl(adv(pu, over), bo3), nv = gl(adv(pv, over), bo3), nw = gl(adv(pw, over), bo2);
-        const VT ns = HAS_S ? gl(adv(ps, over), bo3) : zero;
+        // one / two / three planes up: derived where they are used (three adds, as many as keeping them as running values costs,
+        // and three vector registers less across the level)
+        const unsigned bo1 = bo0 + kk8w, bo2 = bo0 + 2u*kk8w, bo3 = bo0 + 3u*kk8w;
+        const unsigned ovb = FAST ? 0u : (unsigned)over * kk8w;    // (two's complement: a step back of -over planes)
+        const VT nu = gl(pu, bo3 + ovb), nv = gl(pv, bo3 + ovb), nw = gl(pw, bo2 + ovb);
+        const VT ns = HAS_S ? gl(ps, bo3 + ovb) : zero;
 #else
         const VT nu = VT(TF(bo3 + over) * TF(1e-3)), nv = nu + TF(1), nw = nu - TF(1), ns = nu + TF(2);
 #endif
-        if (DSTORE && dsp && active) tst(const_cast<TF*>(adv(pst, -1)), bo0, dss);   // the scalar tendency of level k-1
+        if (DSTORE && dsp && active) tst(pst, bo0 - kk8w, dss);   // the scalar tendency of level k-1
         dsp = false;
         const VT tcu = tpu, tcv = tpv, tcw = tpw, tcs = tps;      // this level's tendencies (loaded during the previous level)
         if constexpr (TPREF) {             // the warm-up level ks = kb-1 fetches those of kb. Unconditional: inactive lanes sit on
             // a clamped (valid) column and plane k+1 <= kend exists, so no lane mask, no select, no register copy
             tpu = tld(put, bo1); tpv = tld(pvt, bo1); tpw = tld(pwt, bo1); if constexpr (HAS_S) tps = tld(pst, bo1); }
+        MHH_STAMP(0);                                             // copies and loads of the next level issued
 
         const LV uk{L + OU + sl(0, RU)*NTILE + l};
         const LV vk{L + OV + sl(0, RU)*NTILE + l};
@@ -421,18 +501,14 @@ rhs25_march_kernel(const GridDev<typename lane_of<VT>::scalar> g, const MarchFie
             Tw = R(rk, sww) * win_cen<RR>(ww, otw);
             if (otw >= 4) Gw = R(rk, tabs(sww)) * win_upw<RR>(ww, otw);
         }
+        copies_at(1);
         VT Du = zero, Dv = zero, Dw = zero, Ds = zero;
         if (DIF && need_dtop)
         {
-            const VT etu = TF(0.25)*(ek[-1] + ek[0] + ekp[-1] + ekp[0]) + visc;
+            const VT etu = quarter_plus(ek[-1] + ek[0] + ekp[-1] + ekp[0], quarter, viscv);
             Du = R(rhkp, etu)*((u0p-u0)*dzhip + (w0p-wkp[-1])*dxd);
-            const VT etv = TF(0.25)*(ek[-TE] + ek[0] + ekp[-TE] + ekp[0]) + visc;
+            const VT etv = quarter_plus(ek[-TE] + ek[0] + ekp[-TE] + ekp[0], quarter, viscv);
             Dv = R(rhkp, etv)*((v0p-v0)*dzhip + (w0p-wkp[-TI])*dyd);
-            if (HAS_S)
-            {
-                const VT ets = div_tpr(ek[0]+ekp[0]) + svisc;
-                Ds = R(rhkp, ets)*(s0p-s0)*dzhip;
-            }
         }
         if (DIF && wlev)
         {
@@ -440,128 +516,182 @@ rhs25_march_kernel(const GridDev<typename lane_of<VT>::scalar> g, const MarchFie
             Dw = R(rk, etw)*(w0p-w0)*dzi;
         }
 
+        copies_at(2);
 #ifdef MHH_EXP_NOMATH          // diagnostic build: the memory traffic alone (copies, loads, stores; one LDS read per plane)
         if ((FAST || k >= kb) && active)
         {
             tst(put, bo0, (TPREF ? tcu : tld(put, bo0)) + uk[0] + ek[0]); tst(pvt, bo0, (TPREF ? tcv : tld(pvt, bo0)) + vk[0]);
             tst(pwt, bo0, (TPREF ? tcw : tld(pwt, bo0)) + wk[0] + wkp[0]); if constexpr (HAS_S) tst(pst, bo0, (TPREF ? tcs : tld(pst, bo0)) + sk[0]);
         }
-        if (false)
+        const bool upd = false;
+#else
+        const bool upd = (FAST || k >= kb) && active;
 #endif
         // ---- update the tendencies of level k ----------------------------------------------------------------
         // (sched_fence between the field sections: the instruction scheduler otherwise hoists every LDS read of a level to
-        //  its top and the level needs more than the 256 registers of two waves per SIMD)
-        if ((FAST || k >= kb) && active)
+        //  its top and the level needs more than the 256 registers of two waves per SIMD; a section is a block of its own under the
+        //  lane mask, so that the copy groups between sections are issued by every lane)
+        // One section per tendency, each a block of its own under the lane mask. `which`: 0 = u, 1 = v, 2 = w, 3 = the scalar.
+        auto section = [&](const int which) __attribute__((always_inline))
         {
-            sched_fence();
-            {   // u
-                VT t = TPREF ? tcu : tld(put, bo0);
-                if constexpr (ADV)
-                {
-                    t += advec25_hor_f0(uk, u0, TI, u0 + u_e, uk[-1] + u0, vk[TI-1] + v_n, vk[-1] + v0, dxih, dyih);
-                    t += vert_combine(otc, obc, Tu, cTu, Gu, cGu, rk, rk1, dzih);
+            if (which == 0)
+            {
+                if (upd)
+                {   // u
+                    VT t = TPREF ? tcu : tld(put, bo0);
+                    if constexpr (ADV)
+                    {
+                        t += advec25_hor_f0(uk, u0, TI, u0 + u_e, uk[-1] + u0, vk[TI-1] + v_n, vk[-1] + v0, dxih, dyih);
+                        t += vert_combine(otc, obc, Tu, cTu, Gu, cGu, rk, rk1, dzih);
+                    }
+                    if constexpr (DIF)
+                    {
+                        const VT ee = ek[0] + visc, ew = ek[-1] + visc;
+                        const VT en = quarter_plus(ek[-1   ] + ek[0  ] + ek[-1+TE] + ek[TE], quarter, viscv);
+                        const VT es = quarter_plus(ek[-1-TE] + ek[-TE] + ek[-1   ] + ek[0 ], quarter, viscv);
+                        const VT hor = + ( ee*(u_e-u0)*dxd - ew*(u0-uk[-1])*dxd ) * dxd2
+                                       + ( en*((uk[TI]-u0    )*dyd + (v_n-vk[TI-1])*dxd)
+                                         - es*((u0    -uk[-TI])*dyd + (v0 -vk[-1  ])*dxd) ) * dyd;
+                        VT ver;
+                        if (fb)      ver = div_rho( Du + rhk * ld2d(f.ufb, ij), rk, rk1 ) * dzi;
+                        else if (ft) ver = div_rho( - rhkp * ld2d(f.uft, ij) - cDu, rk, rk1 ) * dzi;
+                        else         ver = div_rho( Du - cDu, rk, rk1 ) * dzi;
+                        t += hor + ver;
+                    }
+                    tst(put, bo0, t);
                 }
-                if constexpr (DIF)
-                {
-                    const VT ee = ek[0] + visc, ew = ek[-1] + visc;
-                    const VT en = TF(0.25)*(ek[-1   ] + ek[0  ] + ek[-1+TE] + ek[TE]) + visc;
-                    const VT es = TF(0.25)*(ek[-1-TE] + ek[-TE] + ek[-1   ] + ek[0 ]) + visc;
-                    const VT hor = + ( ee*(u_e-u0)*dxd - ew*(u0-uk[-1])*dxd ) * dxd2
-                                   + ( en*((uk[TI]-u0    )*dyd + (v_n-vk[TI-1])*dxd)
-                                     - es*((u0    -uk[-TI])*dyd + (v0 -vk[-1  ])*dxd) ) * dyd;
-                    VT ver;
-                    if (fb)      ver = div_rho( Du + rhk * ld2d(f.ufb, ij), rk, rk1 ) * dzi;
-                    else if (ft) ver = div_rho( - rhkp * ld2d(f.uft, ij) - cDu, rk, rk1 ) * dzi;
-                    else         ver = div_rho( Du - cDu, rk, rk1 ) * dzi;
-                    t += hor + ver;
-                }
-                tst(put, bo0, t);
             }
-            sched_fence();
-            {   // v
-                VT t = TPREF ? tcv : tld(pvt, bo0);
-                if constexpr (ADV)
-                {
-                    t += advec25_hor_f0(vk, v0, TI, uk[1-TI] + u_e, uk[-TI] + u0, v0 + v_n, vk[-TI] + v0, dxih, dyih);
-                    t += vert_combine(otc, obc, Tv, cTv, Gv, cGv, rk, rk1, dzih);
+            else if (which == 1)
+            {
+                if (upd)
+                {   // v
+                    VT t = TPREF ? tcv : tld(pvt, bo0);
+                    if constexpr (ADV)
+                    {
+                        t += advec25_hor_f0(vk, v0, TI, uk[1-TI] + u_e, uk[-TI] + u0, v0 + v_n, vk[-TI] + v0, dxih, dyih);
+                        t += vert_combine(otc, obc, Tv, cTv, Gv, cGv, rk, rk1, dzih);
+                    }
+                    if constexpr (DIF)
+                    {
+                        const VT ee = quarter_plus(ek[-TE  ] + ek[0 ] + ek[1-TE] + ek[1], quarter, viscv);
+                        const VT ew = quarter_plus(ek[-1-TE] + ek[-1] + ek[-TE ] + ek[0], quarter, viscv);
+                        const VT en = ek[0] + visc, es = ek[-TE] + visc;
+                        const VT hor = + ( ee*((vk[1]-v0    )*dxd + (u_e-uk[1-TI])*dyd)
+                                         - ew*((v0   -vk[-1])*dxd + (u0 -uk[-TI ])*dyd) ) * dxd
+                                       + ( en*(v_n-v0)*dyd - es*(v0-vk[-TI])*dyd ) * dyd2;
+                        VT ver;
+                        if (fb)      ver = div_rho( Dv + rhk * ld2d(f.vfb, ij), rk, rk1 ) * dzi;
+                        else if (ft) ver = div_rho( - rhkp * ld2d(f.vft, ij) - cDv, rk, rk1 ) * dzi;
+                        else         ver = div_rho( Dv - cDv, rk, rk1 ) * dzi;
+                        t += hor + ver;
+                    }
+                    tst(pvt, bo0, t);
                 }
-                if constexpr (DIF)
-                {
-                    const VT ee = TF(0.25)*(ek[-TE  ] + ek[0 ] + ek[1-TE] + ek[1]) + visc;
-                    const VT ew = TF(0.25)*(ek[-1-TE] + ek[-1] + ek[-TE ] + ek[0]) + visc;
-                    const VT en = ek[0] + visc, es = ek[-TE] + visc;
-                    const VT hor = + ( ee*((vk[1]-v0    )*dxd + (u_e-uk[1-TI])*dyd)
-                                     - ew*((v0   -vk[-1])*dxd + (u0 -uk[-TI ])*dyd) ) * dxd
-                                   + ( en*(v_n-v0)*dyd - es*(v0-vk[-TI])*dyd ) * dyd2;
-                    VT ver;
-                    if (fb)      ver = div_rho( Dv + rhk * ld2d(f.vfb, ij), rk, rk1 ) * dzi;
-                    else if (ft) ver = div_rho( - rhkp * ld2d(f.vft, ij) - cDv, rk, rk1 ) * dzi;
-                    else         ver = div_rho( Dv - cDv, rk, rk1 ) * dzi;
-                    t += hor + ver;
-                }
-                tst(pvt, bo0, t);
             }
-            sched_fence();
-            if (FAST || k > g.kstart)
-            {   // w
-                VT t = TPREF ? tcw : tld(pwt, bo0);
-                if (HAS_S && f.threfh) { const TF th_k = uniform_load(f.threfh, k); t += f.grav/th_k * (i2(s0m, s0) - th_k); }   // src/thermo_dry.cxx:165-178
-                if constexpr (ADV)
+            else if (which == 2)
+            {
+                if (upd)
                 {
-                    t += advec25_hor_f0(wk, w0, TI, u1m + u_e, u0m + u0, vNm + v_n, v0m + v0, dxih, dyih);
-                    t += vert_combine(otw, obw, Tw, cTw, Gw, cGw, rhk, rhk1, dzhih);
+                    if (FAST || k > g.kstart)
+                    {   // w
+                        VT t = TPREF ? tcw : tld(pwt, bo0);
+                        if (HAS_S && f.threfh) { const TF th_k = uniform_load(f.threfh, k); t += f.grav/th_k * (i2(s0m, s0) - th_k); }   // src/thermo_dry.cxx:165-178
+                        if constexpr (ADV)
+                        {
+                            t += advec25_hor_f0(wk, w0, TI, u1m + u_e, u0m + u0, vNm + v_n, v0m + v0, dxih, dyih);
+                            t += vert_combine(otw, obw, Tw, cTw, Gw, cGw, rhk, rhk1, dzhih);
+                        }
+                        if constexpr (DIF)
+                        {
+                            const VT ee = quarter_plus(ekm[0  ] + ek[0  ] + ekm[1 ] + ek[1 ], quarter, viscv);
+                            const VT ew = quarter_plus(ekm[-1 ] + ek[-1 ] + ekm[0 ] + ek[0 ], quarter, viscv);
+                            const VT en = quarter_plus(ekm[0  ] + ek[0  ] + ekm[TE] + ek[TE], quarter, viscv);
+                            const VT es = quarter_plus(ekm[-TE] + ek[-TE] + ekm[0 ] + ek[0 ], quarter, viscv);
+                            t += + ( ee*((wk[1 ]-w0     )*dxd + (u_e-u1m)*dzhi)
+                                   - ew*((w0    -wk[-1 ])*dxd + (u0 -u0m)*dzhi) ) * dxd
+                                 + ( en*((wk[TI]-w0     )*dyd + (v_n-vNm)*dzhi)
+                                   - es*((w0    -wk[-TI])*dyd + (v0 -v0m)*dzhi) ) * dyd
+                                 + div_rho( Dw - cDw, rhk, rhk1 ) * dzhi2;
+                        }
+                        tst(pwt, bo0, t);
+                    }
                 }
-                if constexpr (DIF)
-                {
-                    const VT ee = TF(0.25)*(ekm[0  ] + ek[0  ] + ekm[1 ] + ek[1 ]) + visc;
-                    const VT ew = TF(0.25)*(ekm[-1 ] + ek[-1 ] + ekm[0 ] + ek[0 ]) + visc;
-                    const VT en = TF(0.25)*(ekm[0  ] + ek[0  ] + ekm[TE] + ek[TE]) + visc;
-                    const VT es = TF(0.25)*(ekm[-TE] + ek[-TE] + ekm[0 ] + ek[0 ]) + visc;
-                    t += + ( ee*((wk[1 ]-w0     )*dxd + (u_e-u1m)*dzhi)
-                           - ew*((w0    -wk[-1 ])*dxd + (u0 -u0m)*dzhi) ) * dxd
-                         + ( en*((wk[TI]-w0     )*dyd + (v_n-vNm)*dzhi)
-                           - es*((w0    -wk[-TI])*dyd + (v0 -v0m)*dzhi) ) * dyd
-                         + div_rho( Dw - cDw, rhk, rhk1 ) * dzhi2;
-                }
-                tst(pwt, bo0, t);
             }
-            sched_fence();
-            if constexpr (HAS_S)
-            {   // scalar
-                VT t = TPREF ? tcs : tld(pst, bo0);
-                if constexpr (ADV)
+            else
+            {
+                // the scalar: its coefficients arrive with the section's LDS reads; the diffusive flux through the top face is formed on
+                // every level (the next level carries it), the tendency on updating levels
+                if constexpr (HAS_S)
                 {
-                    t += advec25_hor_f0(sk, s0, TI, u_e, u0, v_n, v0, dxi, dyi);
-                    t += vert_combine(otc, obc, Ts, cTs, Gs, cGs, rk, rk1, dzi);
+                    const Uniform8<TF> mg1 = uniform_load8(mq + 8);
+                    const TF dxi = mg1.v[0], dyi = mg1.v[1], dxidxi = mg1.v[2], dyidyi = mg1.v[3], svisc = mg1.v[4], tPr2 = mg1.v[5], rtPr2 = mg1.v[6];
+                    auto div_tpr = [&](VT x) -> VT { return div_known(x, tPr2, rtPr2); };     // 0.5*x / tPr
+                    if (DIF && need_dtop)
+                    {
+                        const VT ets = div_tpr(ek[0]+ekp[0]) + svisc;
+                        Ds = R(rhkp, ets)*(s0p-s0)*dzhip;
+                    }
+                    if (upd)
+                    {   // scalar
+                        VT t = TPREF ? tcs : tld(pst, bo0);
+                        if constexpr (ADV)
+                        {
+                            t += advec25_hor_f0(sk, s0, TI, u_e, u0, v_n, v0, dxi, dyi);
+                            t += vert_combine(otc, obc, Ts, cTs, Gs, cGs, rk, rk1, dzi);
+                        }
+                        if constexpr (DIF)
+                        {
+                            const VT e0 = ek[0];
+                            const VT ee = div_tpr(e0     +ek[1 ]) + svisc;
+                            const VT ew = div_tpr(ek[-1 ]+e0    ) + svisc;
+                            const VT en = div_tpr(e0     +ek[TE]) + svisc;
+                            const VT es = div_tpr(ek[-TE]+e0    ) + svisc;
+                            const VT hor = + ( ee*(sk[1 ]-s0) - ew*(s0-sk[-1 ]) ) * dxidxi
+                                           + ( en*(sk[TI]-s0) - es*(s0-sk[-TI]) ) * dyidyi;
+                            VT ver;
+                            if (fb)      ver = div_rho( Ds + rhk * ld2d(f.sfb, ij), rk, rk1 ) * dzi;
+                            else if (ft) ver = div_rho( -rhkp * ld2d(f.sft, ij) - cDs, rk, rk1 ) * dzi;
+                            else         ver = div_rho( Ds - cDs, rk, rk1 ) * dzi;
+                            t += hor + ver;
+                        }
+                        if (DSTORE) dss = t; else tst(pst, bo0, t);           // (dsp is set after the sections: no lane-mask value carried through the section loop)
+                    }
                 }
-                if constexpr (DIF)
-                {
-                    const VT e0 = ek[0];
-                    const VT ee = div_tpr(e0     +ek[1 ]) + svisc;
-                    const VT ew = div_tpr(ek[-1 ]+e0    ) + svisc;
-                    const VT en = div_tpr(e0     +ek[TE]) + svisc;
-                    const VT es = div_tpr(ek[-TE]+e0    ) + svisc;
-                    const VT hor = + ( ee*(sk[1 ]-s0) - ew*(s0-sk[-1 ]) ) * dxidxi
-                                   + ( en*(sk[TI]-s0) - es*(s0-sk[-TI]) ) * dyidyi;
-                    VT ver;
-                    if (fb)      ver = div_rho( Ds + rhk * ld2d(f.sfb, ij), rk, rk1 ) * dzi;
-                    else if (ft) ver = div_rho( -rhkp * ld2d(f.sft, ij) - cDs, rk, rk1 ) * dzi;
-                    else         ver = div_rho( Ds - cDs, rk, rk1 ) * dzi;
-                    t += hor + ver;
-                }
-                if (DSTORE) { dss = t; dsp = true; } else tst(pst, bo0, t);
             }
+        };
+        // MHH_MARCH_ROTSEC: the four waves of a block take the sections in rotated orders (wave w starts with section w). The waves
+        // leave the barrier together and walk the level in lock step: in the same order all four request the same section's LDS reads
+        // at the same time -- 4 x 7 KB through a 128 B/clk pipe -- and every wave waits out the whole burst (~220 cycles per batch,
+        // a third of a level's wave cycles in s_waitcnt lgkmcnt). A tendency is still accumulated in the reference's order: the
+        // rotation only changes WHEN a wave works on which tendency.
+#ifndef MHH_MARCH_ROTSEC
+#define MHH_MARCH_ROTSEC 0
+#endif
+        if constexpr (MHH_MARCH_ROTSEC != 0 && sizeof(TF) == 8)
+        {
+#pragma nounroll
+            for (int n_ = 0; n_ < 4; ++n_) { mfence(); section((n_ + wave_ph) & 3); }
         }
+        else
+        {
+            mfence(); section(0); mfence(); section(1); mfence(); section(2); mfence(); section(3);
+        }
+        if (DSTORE) dsp = upd;
         // ---- carry the top faces down, rotate the windows, advance the plane pointers ------------------------------------
         cTu = Tu; cGu = Gu; cDu = Du; cTv = Tv; cGv = Gv; cDv = Dv; cTw = Tw; cGw = Gw; cDw = Dw; cTs = Ts; cGs = Gs; cDs = Ds;
         u1m = u_e; vNm = v_n;
-        pu = adv(pu, 1); pv = adv(pv, 1); pw = adv(pw, 1); if constexpr (HAS_S) ps = adv(ps, 1); if constexpr (DIF) pe = adv(pe, 1);
-        put = const_cast<TF*>(adv(put, 1)); pvt = const_cast<TF*>(adv(pvt, 1)); pwt = const_cast<TF*>(adv(pwt, 1));
-        if constexpr (HAS_S) pst = const_cast<TF*>(adv(pst, 1));
+#pragma unroll
+        for (int n=0; n<NLD; ++n) off[n] += kk8w;
+#pragma unroll
+        for (int n=0; n<NLDE; ++n) offe[n] += kk8w;
+        bo0 += kk8w;
         // unconditional (also after the chunk's last level, where nothing is in flight): every path back to the loop head
         // then carries a vmcnt(0) the compiler can see, and it inserts no wait of its own in the next level
+        MHH_STAMP(1);                                          // the level's arithmetic, LDS reads, stores
         wait_vmem();                                           // this wave's copies have landed (and its stores have left)
+        MHH_STAMP(2);                                          // waited for memory
         __syncthreads();                                       // ... everyone's have, and everyone is done with the oldest planes
+        MHH_STAMP(3);                                          // waited for the other waves
         if constexpr (ROT < 0) { shift6(uw, nu); shift6(vw, nv); shift6(ww, nw); shift6(sw, ns); }
         else { uw[RR] = nu; vw[RR] = nv; ww[RR] = nw; sw[RR] = ns; }     // the slot of level k-2 takes level k+4: rotation RR+1
     };
@@ -595,8 +725,15 @@ rhs25_march_kernel(const GridDev<typename lane_of<VT>::scalar> g, const MarchFie
     }
     else if (__builtin_expect(rho_one, 1)) chunk(true_type{}, true_type{});
     else              chunk(false_type{}, false_type{});       // anelastic base state: shifted windows (one interior body)
-    if (DSTORE && dsp && active) tst(const_cast<TF*>(adv(pst, -1)), bo0, dss);
+    if (DSTORE && dsp && active) tst(pst, bo0 - kk8w, dss);
+#ifdef MHH_MARCH_STAMP
+    if (tx == 0 && f.dbg) for (int n=0; n<5; ++n) f.dbg[((size_t)blockIdx.x*NJ + ty)*8 + n] = stamp_acc[n];
+    if (tx == 0 && f.dbg) f.dbg[((size_t)blockIdx.x*NJ + ty)*8 + 5] = (unsigned long long)(ke - ks);
+#endif
 }
+#ifdef MHH_MARCH_STAMP
+static unsigned long long* g_stamp_buf = nullptr; static size_t g_stamp_n = 0;
+#endif
 
 // 2 tPr must not have an all-ones significand (div_known, cell_ops.h); 1/3, 1, 0.7 ... have not
 template<class TF> bool known_divisor_ok(TF d)
@@ -623,22 +760,32 @@ int march_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* 
     mf.rhoref = cp<TF>(f->rhoref); mf.rhorefh = cp<TF>(f->rhorefh);
     mf.ufb = cp<TF>(f->u_fluxbot); mf.uft = cp<TF>(f->u_fluxtop); mf.vfb = cp<TF>(f->v_fluxbot); mf.vft = cp<TF>(f->v_fluxtop);
     mf.sfb = has_s ? cp<TF>(f->s_fluxbot[0]) : nullptr; mf.sft = has_s ? cp<TF>(f->s_fluxtop[0]) : nullptr;
-    mf.visc = TF(f->visc); mf.svisc = has_s ? TF(f->svisc[0]) : TF(0); mf.sm = (p && mode != 1) ? p->surface_model : 0;
-    mf.dxi = gd.dxi_t; mf.dyi = gd.dyi_t; mf.dxih = TF(0.5)*gd.dxi_t; mf.dyih = TF(0.5)*gd.dyi_t;
-    mf.dxd = gd.dxi_d; mf.dyd = gd.dyi_d; mf.dxd2 = TF(2.)*gd.dxi_d; mf.dyd2 = TF(2.)*gd.dyi_d;
-    mf.dxidxi = gd.dxidxi_d; mf.dyidyi = gd.dyidyi_d;
+    MarchMetrics<TF> mm;
+    mm.visc = TF(f->visc); mm.svisc = has_s ? TF(f->svisc[0]) : TF(0); mf.sm = (p && mode != 1) ? p->surface_model : 0;
+    mm.dxi = gd.dxi_t; mm.dyi = gd.dyi_t; mm.dxih = TF(0.5)*gd.dxi_t; mm.dyih = TF(0.5)*gd.dyi_t;
+    mm.dxd = gd.dxi_d; mm.dyd = gd.dyi_d; mm.dxd2 = TF(2.)*gd.dxi_d; mm.dyd2 = TF(2.)*gd.dyi_d;
+    mm.dxidxi = gd.dxidxi_d; mm.dyidyi = gd.dyidyi_d; mm.quarter = TF(0.25); mm.pad1 = TF(0);
     const TF tPr = p ? TF(p->tPr) : TF(1);
-    mf.tPr2 = TF(2.)*tPr; mf.rtPr2 = TF(1.)/mf.tPr2;
-    MHH_REQUIRE(mode == 1 || !has_s || known_divisor_ok(mf.tPr2), "tPr must be a positive normal number whose significand is not all ones");
+    mm.tPr2 = TF(2.)*tPr; mm.rtPr2 = TF(1.)/mm.tPr2;
+    MHH_REQUIRE(mode == 1 || !has_s || known_divisor_ok(mm.tPr2), "tPr must be a positive normal number whose significand is not all ones");
     const bool buoy = mode == 0 && has_s && p->buoyancy == 2 && p->th_for_N2 == 0;
     mf.threfh = buoy ? cp<TF>(p->threfh) : nullptr; mf.grav = buoy ? TF(p->grav) : TF(0);
 #ifndef MHH_MARCH_KC
 #define MHH_MARCH_KC 128
 #endif
     // a strip of a few rows (mhh_rhs_exec_rows on the edge rows) takes short k-chunks: enough blocks to fill the GPU
-    const int kc = (j0 >= 0 && (j1 - j0) * 4 <= g->jmax) ? 16 : MHH_MARCH_KC;
+    int kc = (j0 >= 0 && (j1 - j0) * 4 <= g->jmax) ? 16 : MHH_MARCH_KC;
+    // the lanes address a chunk's planes with 32-bit byte offsets from the chunk's first plane: (kc + 8) planes below 4 GB
+    const unsigned long long plane_bytes = (unsigned long long)g->ijcells * sizeof(TF);
+    while (kc > 8 && (unsigned long long)(kc + 8) * plane_bytes >= (1ull << 32)) kc /= 2;
+    MHH_REQUIRE((unsigned long long)(kc + 8) * plane_bytes < (1ull << 32), "a plane of this grid is too large for the marching kernel's 32-bit lane offsets");
     const MarchTiling t = make_march_tiling(g, NJ, kc, j0, j1, 64*CW);
     const unsigned nblocks = march_blocks(t);
+#ifdef MHH_MARCH_STAMP
+    if (g_stamp_n < (size_t)nblocks*NJ*8) { if (g_stamp_buf) (void)hipFree(g_stamp_buf); g_stamp_n = (size_t)nblocks*NJ*8; MHH_HIP_TRY(hipMalloc(&g_stamp_buf, g_stamp_n*8)); }
+    MHH_HIP_TRY(hipMemsetAsync(g_stamp_buf, 0, g_stamp_n*8, st));
+    mf.dbg = g_stamp_buf;
+#endif
     // 16-byte LDS-DMA needs 16-byte aligned plane rows; other layouts copy in 4-byte pieces (MHH_MARCH_DMA=4 forces that
     // form; same arithmetic in both)
     constexpr int VEC = 16 / (int)sizeof(TF);
@@ -647,12 +794,12 @@ int march_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* 
     const bool aligned = (g->icells % VEC == 0) && al16(f->u) && al16(f->v) && al16(f->w) && (mode == 1 || al16(f->evisc)) && (!has_s || al16(f->s[0]));
     const int pb = ((env && !strcmp(env, "4")) || !aligned) ? 4 : 16;
 #define MHH_LAUNCH_MARCH(PBV, A, D) do { \
-        if (has_s) hipLaunchKernelGGL((rhs25_march_kernel<VT, NJ, true, PBV, A, D>),  dim3(nblocks), dim3(64, NJ), 0, st, gd, mf, t); \
-        else       hipLaunchKernelGGL((rhs25_march_kernel<VT, NJ, false, PBV, A, D>), dim3(nblocks), dim3(64, NJ), 0, st, gd, mf, t); } while (0)
+        if (has_s) hipLaunchKernelGGL((rhs25_march_kernel<VT, NJ, true, PBV, A, D>),  dim3(nblocks), dim3(64, NJ), 0, st, mm, gd, mf, t); \
+        else       hipLaunchKernelGGL((rhs25_march_kernel<VT, NJ, false, PBV, A, D>), dim3(nblocks), dim3(64, NJ), 0, st, mm, gd, mf, t); } while (0)
     // tile origin on a 16-byte piece where three cells west of the first cell is not one (istart = 16: rows of whole cache lines)
     const char* ehx = getenv("MHH_MARCH_HX");
     const bool hx4 = mode == 0 && has_s && pb == 16 && (g->istart - 3) % VEC != 0 && (g->istart - 4) % VEC == 0 && g->istart >= 4 && !(ehx && !strcmp(ehx, "3"));
-    if (hx4) hipLaunchKernelGGL((rhs25_march_kernel<VT, NJ, true, 16, true, true, 4>), dim3(nblocks), dim3(64, NJ), 0, st, gd, mf, t);
+    if (hx4) hipLaunchKernelGGL((rhs25_march_kernel<VT, NJ, true, 16, true, true, 4>), dim3(nblocks), dim3(64, NJ), 0, st, mm, gd, mf, t);
     else if (mode == 0) { if (pb == 16) MHH_LAUNCH_MARCH(16, true, true);  else MHH_LAUNCH_MARCH(4, true, true); }
     else if (mode == 1) { if (pb == 16) MHH_LAUNCH_MARCH(16, true, false); else MHH_LAUNCH_MARCH(4, true, false); }
     else                { if (pb == 16) MHH_LAUNCH_MARCH(16, false, true); else MHH_LAUNCH_MARCH(4, false, true); }
@@ -662,6 +809,16 @@ int march_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* 
 }
 } // namespace
 
+#ifdef MHH_MARCH_STAMP
+// probe builds: the stamps of the last launch, [block][wave][8] = cycles issuing | computing | waiting for memory | at the barrier | loop control, levels
+extern "C" __attribute__((visibility("default"))) long long mhh_march_stamps(unsigned long long* host, long long max_n)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    const long long n = (long long)g_stamp_n < max_n ? (long long)g_stamp_n : max_n;
+    if (n > 0 && hipMemcpy(host, g_stamp_buf, (size_t)n*8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return n;
+}
+#endif
 // fp32: two cells per lane with packed arithmetic where the rows are whole 128-cell tiles; MHH_MARCH_F32X2=0 keeps one cell per lane
 static bool f32x2(const mhh_grid* g)
 {

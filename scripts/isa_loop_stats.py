@@ -66,6 +66,15 @@ def main():
                 t = addr_index[tgt]
                 if t < n:
                     loops.append((n - t + 1, t, n))
+        # barrier-to-barrier segments: in the marching kernels one segment = one level (the reliable per-level mix: the loop
+        # ranges below also contain pre-headers and exit paths that sit inside the loop's address range)
+        bars = [n for n, (_, op, _) in enumerate(body) if op.startswith("s_barrier")]
+        for a_, b_ in zip(bars[:-1], bars[1:]):
+            c = Counter(classify(op) for _, op, _ in body[a_:b_])
+            valu = c["valu_f64"] + c["valu_other"] + c["valu_pk"] + c["v_lane"]
+            print("   barrier @%x -> next: %5d instr, VALU %4d (f64 %4d, other %3d, lane %3d)  SALU %3d s_load %2d waitcnt %2d nop %2d branch %2d  LDS %2d DMA %2d gload %2d gstore %2d scratch %d"
+                  % (body[a_][0], b_ - a_, valu, c["valu_f64"], c["valu_other"] + c["valu_pk"], c["v_lane"], c["salu"], c["s_load"], c["s_waitcnt"], c["s_nop"], c["s_branch"],
+                     c["lds"], c["lds_dma"], c["global_load"], c["global_store"], c["scratch"]))
         loops.sort(reverse=True)
         for size, t, n in loops[:6]:
             c = Counter(classify(op) for _, op, _ in body[t:n+1])

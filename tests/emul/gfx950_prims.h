@@ -31,10 +31,14 @@ inline void wave_sync() { __syncthreads(); }     // every thread of the block re
 inline double recip_seed(double x) { return 1./x; }
 inline float  recip_seed(float x)  { return 1.f/x; }
 inline void keep_vgpr(unsigned&) {}
+template<class T> inline void pin_vgpr(T&) {}
 template<class T> inline T gload(const T* b, unsigned o) { return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(b) + o); }
 template<class T> inline T gload_stream(const T* b, unsigned o) { return gload(b, o); }
 template<class T> inline void gstore(T* b, unsigned o, T v) { *reinterpret_cast<T*>(reinterpret_cast<char*>(b) + o) = v; }
 template<class T> inline void gstore_stream(T* b, unsigned o, T v) { gstore(b, o, v); }
 template<class T> inline T uniform_load(const T* table, int idx) { return table[idx]; }
+template<class T> struct alignas(16) Uniform8 { T v[8]; };
+template<class T> inline Uniform8<T> uniform_load8(const T* table) { Uniform8<T> r; for (int n=0; n<8; ++n) r.v[n] = table[n]; return r; }
+template<class T> inline const T* first_kernarg(const T& first_argument) { return &first_argument; }
 
 }
