@@ -12,6 +12,8 @@
 // real tridiagonal system per wave-number pair (the matrix is real and depends only on
 // bmati[kx]+bmatj[ky]), so results agree to rounding of the transform (DESIGN.md "Parity").
 #include <vector>
+#include <map>
+#include <mutex>
 #include <rocfft/rocfft.h>
 #include "fft_lifetime.h"
 #include <cstring>
@@ -880,13 +882,21 @@ static int pres_exec_fused(mhh_pres_plan* P, const mhh_grid* g, const mhh_fields
 #ifndef MHH_PRES_LDS_RG
 #define MHH_PRES_LDS_RG 2          // rows whose loads a thread of the x-stage kernels keeps in flight together
 #endif
-#ifndef MHH_PRES_LDS_BT
-#define MHH_PRES_LDS_BT 1024       // largest block (= itot) of the x-stage kernels: bounds their registers
-#endif
-static constexpr int LDS_RG = MHH_PRES_LDS_RG, LDS_BT = MHH_PRES_LDS_BT;
-// the transform sizes compiled with constant strides (the benchmark grids): itot = 512 in double, itot = 1024 in single precision;
-// jtot = 512 (at 1024 the unrolled passes no longer fit the 128 registers of a 1024-thread block). Everything else runs the same kernels with the sizes as run-time values.
-template<class TF> static constexpr int lds_nx_ct() { return sizeof(TF) == 8 ? 8 : 9; }
+static constexpr int LDS_RG = MHH_PRES_LDS_RG;
+// Every power-of-two row length has an instantiation of its own with the transform's strides as compile-time constants and a
+// block of exactly that many threads (round 2 had one per precision, the benchmark's; every other shape took run-time-size kernels
+// whose fp64 forms spilled at the 128 registers of a 1024-thread block). X rows: itot = 128 ... 1024 (NX = log2(itot/2) = 6 ... 9),
+// y rows: jtot = 64 ... 1024 (NY = 6 ... 10); shorter rows (tests, toy grids) run the run-time-size kernels in small blocks, where
+// registers are plentiful. Launch bounds keep at least 1024 threads per CU resident. An instantiation that needs scratch on this
+// compiler is not used (hipFuncGetAttributes at plan creation): the plan then has no LDS form and takes the staged one.
+#define MHH_FOR_NX(M) M(6) M(7) M(8) M(9)
+#define MHH_FOR_NY(M) M(6) M(7) M(8) M(9) M(10)
+#define MHH_FOR_NX_T(M, T) M(T, 6) M(T, 7) M(T, 8) M(T, 9)
+#define MHH_FOR_NY_T(M, T) M(T, 6) M(T, 7) M(T, 8) M(T, 9) M(T, 10)
+// (fp64 rows of 1024 along y: the unrolled passes do not fit the 128 registers of a 1024-thread block -- 88 bytes of scratch -- so
+// that size has no instantiation and such grids take the staged form)
+template<class TF, int NY> static constexpr bool lds_has_ny() { return sizeof(TF) == 4 || NY < 10; }
+static constexpr int LDS_XS = 64, LDS_YS = 32;            // block sizes of the run-time-size forms (itot <= 64, jtot <= 32)
 static int ilog2(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
 // rows of the transforms + the twiddle table; the 9-row kernel (stage 3) also keeps p of the level below there (8 rows of itot reals)
 static size_t lds_bytes_x(const mhh_pres_plan* P, int rows) { return ((size_t)rows*(P->itot/2 + 2) + P->itot) * 2*P->esz + (rows == 9 ? (size_t)8*P->itot*P->esz : 0); }
@@ -897,9 +907,58 @@ static lds_fft::PresLdsSolve<TF> lds_solve_args(const mhh_pres_plan* P)
     return lds_fft::PresLdsSolve<TF>{static_cast<C2<TF>*>(P->spec), cp<TF>(P->w3l), cp<TF>(P->bmati), cp<TF>(P->bmatj), cp<TF>(P->a), cp<TF>(P->c),
                                      cp<TF>(P->dz), cp<TF>(P->rhoref), static_cast<const C2<TF>*>(P->ty), P->itot/2, P->jtot, ilog2(P->jtot), P->ktot};
 }
+// the kernel of a stage for a row length: NX / NY = 0 selects the run-time-size form
+template<class TF, int NX> static const void* lds_kernel_in()  { return reinterpret_cast<const void*>(&lds_fft::pres_in_fftx_kernel<TF, LDS_RG, (NX ? (2 << NX) : LDS_XS), NX>); }
+template<class TF, int NX> static const void* lds_kernel_out() { return reinterpret_cast<const void*>(&lds_fft::pres_ifftx_out_kernel<TF, LDS_RG, (NX ? (2 << NX) : LDS_XS), NX>); }
+template<class TF, int NY> static const void* lds_kernel_y()   { return reinterpret_cast<const void*>(&lds_fft::pres_ysolve_kernel<TF, (NY ? (1 << NY) : LDS_YS), NY>); }
+// once per process and kernel: the dynamic-LDS ceiling at the device's maximum (the attribute belongs to the FUNCTION, not to a
+// plan: set per plan to that plan's bytes, a small plan created after a large one lowered the ceiling under the large one), and
+// whether the instantiation needs scratch
+static int lds_kernel_ready(const void* kernel, bool& usable)
+{
+    static std::map<const void*, bool> seen;
+    static std::mutex mtx;
+    std::lock_guard<std::mutex> lock(mtx);
+    auto it = seen.find(kernel);
+    if (it == seen.end())
+    {
+        MHH_HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024));
+        hipFuncAttributes fa;
+        MHH_HIP_TRY(hipFuncGetAttributes(&fa, kernel));
+        it = seen.emplace(kernel, fa.localSizeBytes == 0).first;
+    }
+    usable = it->second;
+    return MHH_OK;
+}
+template<class TF>
+static int pres_lds_kernels_ready(const mhh_pres_plan* P, bool& usable)
+{
+    const int nx = ilog2(P->itot/2), ny = ilog2(P->jtot);
+    const void* k[3] = {nullptr, nullptr, nullptr};
+    if (P->itot <= LDS_XS) { k[0] = lds_kernel_in<TF, 0>(); k[1] = lds_kernel_out<TF, 0>(); }
+    if (P->jtot <= LDS_YS) k[2] = lds_kernel_y<TF, 0>();
+#define M(N) if (nx == N) { k[0] = lds_kernel_in<TF, N>(); k[1] = lds_kernel_out<TF, N>(); }
+    MHH_FOR_NX(M)
+#undef M
+#define M(N) if (ny == N) { if constexpr (lds_has_ny<TF, N>()) k[2] = lds_kernel_y<TF, N>(); }
+    MHH_FOR_NY(M)
+#undef M
+    usable = true;
+    for (int n=0; n<3; ++n)
+    {
+        if (!k[n]) { usable = false; return MHH_OK; }
+        bool u = false;
+        if (int e = lds_kernel_ready(k[n], u)) return e;
+        usable = usable && u;
+    }
+    return MHH_OK;
+}
 template<class TF>
 static int pres_lds_setup_t(mhh_pres_plan* P)
 {
+    bool usable = false;
+    if (int e = pres_lds_kernels_ready<TF>(P, usable)) return e;
+    if (!usable) return MHH_OK;
     const double pi = std::acos(-1.);
     for (int d=0; d<2; ++d)
     {
@@ -915,25 +974,17 @@ static int pres_lds_setup_t(mhh_pres_plan* P)
     hipLaunchKernelGGL(lds_fft::pres_lds_factor_kernel<TF>, dim3((P->jtot + 63)/64, P->itot/2 + 1), dim3(64), 0, 0, static_cast<TF*>(P->w3l), lds_solve_args<TF>(P));
     MHH_LAUNCH_CHECK();
     MHH_HIP_TRY(hipStreamSynchronize(0));
-    const int bx8 = (int)lds_bytes_x(P, 8), bx9 = (int)lds_bytes_x(P, 9), by = (int)lds_bytes_y(P);
-#define LDS_ATTR(kernel, bytes) MHH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes))
-    LDS_ATTR((lds_fft::pres_in_fftx_kernel<TF, LDS_RG, LDS_BT, 0>), bx8);   LDS_ATTR((lds_fft::pres_in_fftx_kernel<TF, LDS_RG, LDS_BT, lds_nx_ct<TF>()>), bx8);
-    LDS_ATTR((lds_fft::pres_ifftx_out_kernel<TF, LDS_RG, LDS_BT, 0>), bx9); LDS_ATTR((lds_fft::pres_ifftx_out_kernel<TF, LDS_RG, LDS_BT, lds_nx_ct<TF>()>), bx9);
-    LDS_ATTR((lds_fft::pres_ysolve_kernel<TF, 512, 0>), by); LDS_ATTR((lds_fft::pres_ysolve_kernel<TF, 1024, 0>), by);
-    LDS_ATTR((lds_fft::pres_ysolve_kernel<TF, 512, 9>), by);
-#undef LDS_ATTR
+    P->lds_ok = true;
     return MHH_OK;
 }
 static int pres_lds_setup(mhh_pres_plan* P, const mhh_grid* g)
 {
     const size_t lds_max = 160*1024;
-    if (!(is_pow2(P->itot) && P->itot >= 16 && P->itot <= LDS_BT && is_pow2(P->jtot) && P->jtot >= 8 && P->jtot <= 1024)) return MHH_OK;
+    if (!(is_pow2(P->itot) && P->itot >= 16 && P->itot <= 1024 && is_pow2(P->jtot) && P->jtot >= 8 && P->jtot <= 1024)) return MHH_OK;
     if (lds_bytes_x(P, 9) > lds_max || lds_bytes_y(P) > lds_max) return MHH_OK;
     if (g->igc > P->itot || g->jgc > P->jtot) return MHH_OK;
     if ((long long)g->icells*g->jcells*g->kcells >= (1ll << 31)) return MHH_OK;        // the x-stage kernels index cells with 32 bits
-    if (int e = (P->dtype == MHH_F64) ? pres_lds_setup_t<double>(P) : pres_lds_setup_t<float>(P)) return e;
-    P->lds_ok = true;
-    return MHH_OK;
+    return (P->dtype == MHH_F64) ? pres_lds_setup_t<double>(P) : pres_lds_setup_t<float>(P);
 }
 static int lds_levels_per_block(const mhh_pres_plan* P)
 {
@@ -953,36 +1004,42 @@ MHH_API int mhh_pres_lds_stage(mhh_pres_plan* P, const mhh_grid* g, const mhh_fi
     hipStream_t st = as_stream(stream);
     const int kc = lds_levels_per_block(P);
     const dim3 xgrid((unsigned)(P->jtot/8) * (unsigned)((P->ktot + kc-1)/kc));        // strips x chunks, decoded by lds_strip_of_block
+    const int nx = ilog2(P->itot/2), ny = ilog2(P->jtot);
     if (stage == 1)
     {
         MHH_REQUIRE(f && f->u && f->v && f->w && f->ut && f->vt && f->wt && f->rhoref && f->rhorefh, "null field");
         MHH_REQUIRE(dt > 0., "dt");
         if (int e = pres_input_halos(g, 2, f, stream)) return e;
+#define M(TF, N) else if (nx == N) hipLaunchKernelGGL((lds_fft::pres_in_fftx_kernel<TF, LDS_RG, (2 << N), N>), xgrid, dim3(P->itot), lds_bytes_x(P, 8), st, a);
 #define CALL(TF) [&]{ lds_fft::PresLdsIn<TF> a{make_grid<TF>(g), cp<TF>(f->u), cp<TF>(f->v), cp<TF>(f->w), cp<TF>(f->ut), cp<TF>(f->vt), cp<TF>(f->wt), \
-                          cp<TF>(f->rhoref), cp<TF>(f->rhorefh), TF(1.)/TF(dt), static_cast<C2<TF>*>(P->spec), static_cast<const C2<TF>*>(P->tx), ilog2(P->itot/2), kc}; \
-                      if (a.nx == lds_nx_ct<TF>()) hipLaunchKernelGGL((lds_fft::pres_in_fftx_kernel<TF, LDS_RG, LDS_BT, lds_nx_ct<TF>()>), xgrid, dim3(P->itot), lds_bytes_x(P, 8), st, a); \
-                      else hipLaunchKernelGGL((lds_fft::pres_in_fftx_kernel<TF, LDS_RG, LDS_BT, 0>), xgrid, dim3(P->itot), lds_bytes_x(P, 8), st, a); return MHH_OK; }()
+                          cp<TF>(f->rhoref), cp<TF>(f->rhorefh), TF(1.)/TF(dt), static_cast<C2<TF>*>(P->spec), static_cast<const C2<TF>*>(P->tx), nx, kc}; \
+                      if (P->itot <= LDS_XS) hipLaunchKernelGGL((lds_fft::pres_in_fftx_kernel<TF, LDS_RG, LDS_XS, 0>), xgrid, dim3(P->itot), lds_bytes_x(P, 8), st, a); \
+                      MHH_FOR_NX_T(M, TF) return MHH_OK; }()
         if (int e = MHH_DISPATCH(g, CALL)) return e;
 #undef CALL
+#undef M
     }
     else if (stage == 2)
     {
+#define M(TF, N) else if (ny == N) { if constexpr (lds_has_ny<TF, N>()) hipLaunchKernelGGL((lds_fft::pres_ysolve_kernel<TF, (1 << N), N>), yg, yb, yl, st, ya); }
 #define CALL(TF) [&]{ const dim3 yg(P->itot/2), yb(P->jtot); const size_t yl = lds_bytes_y(P); const auto ya = lds_solve_args<TF>(P); \
-                      if (P->jtot == 512)       hipLaunchKernelGGL((lds_fft::pres_ysolve_kernel<TF, 512, 9>), yg, yb, yl, st, ya); \
-                      else if (P->jtot < 512)   hipLaunchKernelGGL((lds_fft::pres_ysolve_kernel<TF, 512, 0>), yg, yb, yl, st, ya); \
-                      else                      hipLaunchKernelGGL((lds_fft::pres_ysolve_kernel<TF, 1024, 0>), yg, yb, yl, st, ya); return MHH_OK; }()
+                      if (P->jtot <= LDS_YS) hipLaunchKernelGGL((lds_fft::pres_ysolve_kernel<TF, LDS_YS, 0>), yg, yb, yl, st, ya); \
+                      MHH_FOR_NY_T(M, TF) return MHH_OK; }()
         if (int e = MHH_DISPATCH(g, CALL)) return e;
 #undef CALL
+#undef M
     }
     else
     {
         MHH_REQUIRE(f && f->p && f->ut && f->vt && f->wt, "null field");
+#define M(TF, N) else if (nx == N) hipLaunchKernelGGL((lds_fft::pres_ifftx_out_kernel<TF, LDS_RG, (2 << N), N>), xgrid, dim3(P->itot), lds_bytes_x(P, 9), st, a);
 #define CALL(TF) [&]{ lds_fft::PresLdsOut<TF> a{make_grid<TF>(g), static_cast<const C2<TF>*>(P->spec), static_cast<const C2<TF>*>(P->tx), \
-                          mp<TF>(f->p), mp<TF>(f->ut), mp<TF>(f->vt), mp<TF>(f->wt), ilog2(P->itot/2), kc}; \
-                      if (a.nx == lds_nx_ct<TF>()) hipLaunchKernelGGL((lds_fft::pres_ifftx_out_kernel<TF, LDS_RG, LDS_BT, lds_nx_ct<TF>()>), xgrid, dim3(P->itot), lds_bytes_x(P, 9), st, a); \
-                      else hipLaunchKernelGGL((lds_fft::pres_ifftx_out_kernel<TF, LDS_RG, LDS_BT, 0>), xgrid, dim3(P->itot), lds_bytes_x(P, 9), st, a); return MHH_OK; }()
+                          mp<TF>(f->p), mp<TF>(f->ut), mp<TF>(f->vt), mp<TF>(f->wt), nx, kc}; \
+                      if (P->itot <= LDS_XS) hipLaunchKernelGGL((lds_fft::pres_ifftx_out_kernel<TF, LDS_RG, LDS_XS, 0>), xgrid, dim3(P->itot), lds_bytes_x(P, 9), st, a); \
+                      MHH_FOR_NX_T(M, TF) return MHH_OK; }()
         if (int e = MHH_DISPATCH(g, CALL)) return e;
 #undef CALL
+#undef M
     }
     MHH_LAUNCH_CHECK();
     return MHH_OK;
@@ -997,7 +1054,11 @@ MHH_API int mhh_pres_exec_form(const mhh_pres_plan* P)
 {
     if (!P || !P->lds_ok) return 0;
     const char* le = getenv("MHH_PRES_LDS");
-    const bool lds_large = (long long)P->itot*P->jtot*P->ktot >= (1ll << 26) && P->itot >= 512;
+    // measured on MI355X with every row length in its own instantiation (profiles/r3_pres_forms.md; ms staged / LDS form):
+    // 128^3 0.137 / 0.184, 256^3 0.742 / 0.688, 256x256x512 1.55 / 1.43, 512x256x256 1.38 / 1.16, 512x512x128 1.44 / 1.12,
+    // 512^3 5.80 / 4.05, 1024x512x256 6.00 / 4.60; fp32 256^3 0.472 / 0.464, 512^3 3.68 / 2.42, 1024x1024x256 7.81 / 4.61:
+    // the LDS form from 2^24 cells on (below that the arrays sit in the Infinity Cache and the staged passes are cheap)
+    const bool lds_large = (long long)P->itot*P->jtot*P->ktot >= (1ll << 24);
     return (le ? !strcmp(le, "1") : lds_large) ? 1 : 0;
 }
 MHH_API int mhh_pres_exec(mhh_pres_plan* P, const mhh_grid* g, const mhh_fields* f, double dt, void* stream)

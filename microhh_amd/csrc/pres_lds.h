@@ -215,7 +215,7 @@ struct PresLdsIn
     int kc;                           // levels per block
 };
 template<class TF, int RG, int BT, int NX>
-__global__ void __launch_bounds__(BT) pres_in_fftx_kernel(const PresLdsIn<TF> a)
+__global__ void __launch_bounds__(BT, (BT >= 128 ? 4 : 1)) pres_in_fftx_kernel(const PresLdsIn<TF> a)
 {
     HIP_DYNAMIC_SHARED(LdsUnit, lds_raw);
     const GridDev<TF>& g = a.g;
@@ -539,7 +539,7 @@ struct PresLdsOut
     int nx, kc;
 };
 template<class TF, int RG, int BT, int NX>
-__global__ void __launch_bounds__(BT) pres_ifftx_out_kernel(const PresLdsOut<TF> a)
+__global__ void __launch_bounds__(BT, (BT >= 128 ? 4 : 1)) pres_ifftx_out_kernel(const PresLdsOut<TF> a)
 {
     HIP_DYNAMIC_SHARED(LdsUnit, lds_raw);
     const GridDev<TF>& g = a.g;

@@ -20,7 +20,10 @@ for it in range(n):
     order = 2 if rng.random() < 0.6 else 4
     itot = int(rng.choice([4, 6, 8, 12, 16, 20, 30, 32, 48, 64])); jtot = int(rng.choice([1, 3, 4, 6, 8, 10, 16, 24])); ktot = int(rng.integers(4, 24))
     if lds:
-        order = 2; itot = int(rng.choice([16, 32, 64, 128, 256, 512])); jtot = int(rng.choice([8, 16, 32, 64, 128, 256])); ktot = int(rng.integers(2, 40))
+        # every instantiated row length (csrc/k_pres.hip): itot 16 ... 1024, jtot 8 ... 1024 (fp64: ... 512); few levels on the big planes
+        order = 2; itot = int(rng.choice([16, 32, 64, 128, 256, 512, 1024])); jtot = int(rng.choice([8, 16, 32, 64, 128, 256, 512, 1024]))
+        if dtype == np.float64 and jtot == 1024: jtot = 512
+        ktot = int(rng.integers(2, 40)) if itot*jtot <= 128*128 else int(rng.integers(2, 9))
         os.environ["MHH_PRES_LDS"] = "1"; os.environ["MHH_PRES_LDS_KC"] = str(int(rng.integers(1, 12)))
     if order == 2:
         g = cm.grid_2nd(itot, jtot, ktot, gc=(int(rng.integers(1, 4)), int(rng.integers(1, 4)), 1), dtype=dtype)

@@ -37,6 +37,8 @@ extern double g_emul_dyn_lds[160*1024/8];
 #define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(g_emul_dyn_lds);
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize };
 inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return 0; }
+struct hipFuncAttributes { size_t localSizeBytes = 0; };
+inline hipError_t hipFuncGetAttributes(hipFuncAttributes* a, const void*) { a->localSizeBytes = 0; return 0; }
 
 // Execution model: every simulated thread of a block is a fiber (ucontext). A fiber runs until it finishes or
 // reaches __syncthreads(), which yields to the scheduler; the scheduler resumes the block's fibers round-robin,

@@ -573,6 +573,88 @@ def test_pres2_lds_transform_form(be, dtype):
     be.lib.mhh_pres_plan_destroy(plan)
 
 
+def _lds_form_against_oracle(be, shape, gc, dtype, tol):
+    """Pres_2::exec in the LDS-transform form on one grid against the oracle's input -> solve -> output."""
+    O = cm.oracle()
+    g = cm.grid_2nd(*shape, gc=gc, dtype=dtype)
+    c = cm.Case(g, rho="random", periodic=True); Gh = g.host_struct(); dt = 0.7
+    d = B.DevCase(be, c); f = d.fields()
+    plan = capi.PLAN()
+    B.ok(be, be.lib.mhh_pres_plan_create(Gh, 2, ptr(g.dz), ptr(g.dzhi), ptr(g.dzi4), ptr(g.dzhi4), ptr(c.rhoref), ptr(c.rhorefh), C.byref(plan)))
+    try:
+        assert be.lib.mhh_pres_plan_has_lds_form(plan) == 1, shape
+        os.environ["MHH_PRES_LDS"] = "1"
+        try:
+            B.ok(be, be.lib.mhh_pres_exec(plan, d.G, C.byref(f), dt, be.stream))
+        finally:
+            os.environ.pop("MHH_PRES_LDS", None)
+        pk = np.zeros((g.ktot, g.jtot, g.itot), dtype=dtype); p_want = np.zeros(g.shape3, dtype=dtype)
+        ut, vt, wt = c.ut.copy(), c.vt.copy(), c.wt.copy()
+        O.orc_pres_input(Gh, 2, ptr(pk), ptr(c.u), ptr(c.v), ptr(c.w), ptr(ut), ptr(vt), ptr(wt), ptr(c.rhoref), ptr(c.rhorefh), dbl(dt))
+        O.orc_pres_solve(Gh, 2, ptr(p_want), ptr(pk), ptr(c.rhoref), ptr(c.rhorefh))
+        O.orc_pres_output(Gh, 2, ptr(ut), ptr(vt), ptr(wt), ptr(p_want))
+        sl = (slice(g.kstart-1, g.kend), slice(None), slice(None))
+        pscale = np.abs(p_want).max()
+        err = np.abs(be.host(d.p)[sl] - p_want[sl]).max() / pscale
+        assert err <= tol, (shape, err)
+        for got_t, want_t, nm in ((d.ut, ut, "ut"), (d.vt, vt, "vt"), (d.wt, wt, "wt")):
+            assert np.abs(be.host(got_t) - want_t).max() <= tol*max(np.abs(want_t).max(), pscale/float(min(g.dx, g.dy))), (shape, nm)
+    finally:
+        be.lib.mhh_pres_plan_destroy(plan)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pres2_lds_form_at_every_instantiated_row_length(dtype):
+    """The compile-time-size instantiations of the three kernels (itot = 128 ... 1024, jtot = 64 ... 1024; csrc/k_pres.hip) each
+    against the ORACLE directly, the benchmark's among them: 512 x 512 (fp64, drycblles 512^3) and 1024 x 512 / 1024 x 1024 (fp32,
+    gabls1). A few levels suffice: the transforms are per level, the vertical solve is covered by the small cases. GPU only: a
+    1024-thread block is a thousand fibres per block on the emulation."""
+    be = B.get("hip")
+    tol = 1e-11 if dtype == np.float64 else 2e-4
+    shapes = [(512, 512, 6), (256, 256, 5), (128, 64, 7), (1024, 128, 4), (256, 512, 4), (512, 256, 9)]
+    shapes += [(1024, 512, 4), (128, 1024, 3), (1024, 1024, 3)] if dtype == np.float32 else [(1024, 512, 3)]
+    for shape in shapes:
+        _lds_form_against_oracle(be, shape, (3, 3, 1), dtype, tol)
+    if dtype == np.float64:     # fp64 rows of 1024 along y have no instantiation (scratch): the plan says so and mhh_pres_exec takes the staged form
+        g = cm.grid_2nd(128, 1024, 3, gc=(3, 3, 1), dtype=dtype); c = cm.Case(g, rho="random", periodic=True)
+        plan = capi.PLAN()
+        B.ok(be, be.lib.mhh_pres_plan_create(g.host_struct(), 2, ptr(g.dz), ptr(g.dzhi), ptr(g.dzi4), ptr(g.dzhi4), ptr(c.rhoref), ptr(c.rhorefh), C.byref(plan)))
+        assert be.lib.mhh_pres_plan_has_lds_form(plan) == 0 and be.lib.mhh_pres_exec_form(plan) == 0
+        be.lib.mhh_pres_plan_destroy(plan)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pres2_lds_plans_of_different_sizes_do_not_disturb_each_other(be, dtype):
+    """The dynamic-LDS ceiling is a property of the kernel, not of the plan: a large plan, then a small plan of the same
+    instantiation family, then the large plan again (the small plan used to lower the ceiling under the large one)."""
+    tol = 1e-11 if dtype == np.float64 else 2e-4
+    O = cm.oracle()
+    gl, gs = cm.grid_2nd(64, 32, 6, gc=(3, 3, 1), dtype=dtype), cm.grid_2nd(16, 8, 6, gc=(3, 3, 1), dtype=dtype)
+    cl, cs = cm.Case(gl, rho="random", periodic=True), cm.Case(gs, rho="random", periodic=True)
+    plans = []
+    for g, c in ((gl, cl), (gs, cs)):
+        plan = capi.PLAN()
+        B.ok(be, be.lib.mhh_pres_plan_create(g.host_struct(), 2, ptr(g.dz), ptr(g.dzhi), ptr(g.dzi4), ptr(g.dzhi4), ptr(c.rhoref), ptr(c.rhorefh), C.byref(plan)))
+        plans.append(plan)
+    os.environ["MHH_PRES_LDS"] = "1"
+    try:
+        for g, c, plan in ((gl, cl, plans[0]), (gs, cs, plans[1]), (gl, cl, plans[0])):
+            d = B.DevCase(be, c); f = d.fields(); dt = 0.7
+            B.ok(be, be.lib.mhh_pres_exec(plan, d.G, C.byref(f), dt, be.stream))
+            Gh = g.host_struct()
+            pk = np.zeros((g.ktot, g.jtot, g.itot), dtype=dtype); p_want = np.zeros(g.shape3, dtype=dtype)
+            ut, vt, wt = c.ut.copy(), c.vt.copy(), c.wt.copy()
+            O.orc_pres_input(Gh, 2, ptr(pk), ptr(c.u), ptr(c.v), ptr(c.w), ptr(ut), ptr(vt), ptr(wt), ptr(c.rhoref), ptr(c.rhorefh), dbl(dt))
+            O.orc_pres_solve(Gh, 2, ptr(p_want), ptr(pk), ptr(c.rhoref), ptr(c.rhorefh))
+            sl = (slice(g.kstart-1, g.kend), slice(None), slice(None))
+            assert np.abs(be.host(d.p)[sl] - p_want[sl]).max() <= tol*np.abs(p_want).max(), g.shape3
+    finally:
+        os.environ.pop("MHH_PRES_LDS", None)
+        for plan in plans:
+            be.lib.mhh_pres_plan_destroy(plan)
+
+
 @pytest.mark.parametrize("adv,dif", [(cm.ADVEC_2I4, cm.DIFF_2), (cm.ADVEC_2I62, cm.DIFF_SMAG2), (cm.ADVEC_2I53, cm.DIFF_SMAG2), (cm.ADVEC_4M, cm.DIFF_4)])
 def test_rhs_exec_other_scheme_pairs_run_as_two_calls(be, adv, dif):
     """mhh_rhs_exec accepts every pair of valid schemes: pairs without a fused kernel run Advec::exec then Diff::exec."""
