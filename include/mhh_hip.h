@@ -335,6 +335,16 @@ int mhh_pres_solve_y         (mhh_pres_slab_plan* plan, const mhh_grid* g, void*
 int mhh_pres_bwd_y_chunk     (mhh_pres_slab_plan* plan, const mhh_grid* g, void* sendbuf, int c, void* stream);
 int mhh_pres_bwd_x_chunk     (mhh_pres_slab_plan* plan, const mhh_grid* g, void* recvbuf, int c, void* stream);
 int mhh_pres_unpack_output_slab(mhh_pres_slab_plan* plan, const mhh_grid* g, const mhh_fields* f, void* stream);
+/* The x stages of the slab solve with the transforms in LDS (csrc/pres_lds.h; power-of-two itot, jmax a multiple of 8;
+ * mhh_pres_slab_has_lds tells): Pres_2::input + the transform along x (src/pres_2.cxx:156-196, src/fft.cxx:451-497) of k-slice c
+ * written straight into segment c of the send buffer of Transpose::exec_xy (src/transpose.cxx:170-193), and the transform back
+ * along x + p with its x halo + Pres_2::output (src/fft.cxx:540-583, src/pres_2.cxx:333-387) read straight from segment c of the
+ * receive buffer of Transpose::exec_yx. They replace mhh_pres_input_packed + fwd_x_pack[_chunk] and bwd_x[_chunk] +
+ * unpack_output_slab; the y stage, the one-row halo of p and mhh_pres_output_south_row stay. c = 0 with unsliced transposes.
+ * Same tolerance as the staged form (different transforms, not the same bits). */
+int mhh_pres_slab_has_lds(const mhh_pres_slab_plan* plan);
+int mhh_pres_slab_lds_fwd(mhh_pres_slab_plan* plan, const mhh_grid* g, const mhh_fields* f, double dt, void* sendbuf, int c, void* stream);
+int mhh_pres_slab_lds_bwd(mhh_pres_slab_plan* plan, const mhh_grid* g, const void* recvbuf, const mhh_fields* f, int c, void* stream);
 
 /* ---- Vertical ghost cells --------------------------------------------------------------
  * Boundary::set_ghost_cells: calc_ghost_cells_{bot,top}_{2nd,4th} (src/boundary.cxx:686-836); bc 0 = Dirichlet

@@ -113,6 +113,9 @@ SIGNATURES = {
     "mhh_pres_bwd_y_chunk": (ci, [PLAN, GP, vp, ci, vp]),
     "mhh_pres_bwd_x_chunk": (ci, [PLAN, GP, vp, ci, vp]),
     "mhh_pres_unpack_output_slab": (ci, [PLAN, GP, FP, vp]),
+    "mhh_pres_slab_has_lds": (ci, [PLAN]),
+    "mhh_pres_slab_lds_fwd": (ci, [PLAN, GP, FP, C.c_double, vp, ci, vp]),
+    "mhh_pres_slab_lds_bwd": (ci, [PLAN, GP, vp, FP, ci, vp]),
 }
 
 

@@ -1012,7 +1012,7 @@ MHH_API int mhh_pres_lds_stage(mhh_pres_plan* P, const mhh_grid* g, const mhh_fi
         if (int e = pres_input_halos(g, 2, f, stream)) return e;
 #define M(TF, N) else if (nx == N) hipLaunchKernelGGL((lds_fft::pres_in_fftx_kernel<TF, LDS_RG, (2 << N), N>), xgrid, dim3(P->itot), lds_bytes_x(P, 8), st, a);
 #define CALL(TF) [&]{ lds_fft::PresLdsIn<TF> a{make_grid<TF>(g), cp<TF>(f->u), cp<TF>(f->v), cp<TF>(f->w), cp<TF>(f->ut), cp<TF>(f->vt), cp<TF>(f->wt), \
-                          cp<TF>(f->rhoref), cp<TF>(f->rhorefh), TF(1.)/TF(dt), static_cast<C2<TF>*>(P->spec), static_cast<const C2<TF>*>(P->tx), nx, kc}; \
+                          cp<TF>(f->rhoref), cp<TF>(f->rhorefh), TF(1.)/TF(dt), static_cast<C2<TF>*>(P->spec), static_cast<const C2<TF>*>(P->tx), nx, kc, 0, P->ktot, P->jtot, {}}; \
                       if (P->itot <= LDS_XS) hipLaunchKernelGGL((lds_fft::pres_in_fftx_kernel<TF, LDS_RG, LDS_XS, 0>), xgrid, dim3(P->itot), lds_bytes_x(P, 8), st, a); \
                       MHH_FOR_NX_T(M, TF) return MHH_OK; }()
         if (int e = MHH_DISPATCH(g, CALL)) return e;
@@ -1034,7 +1034,7 @@ MHH_API int mhh_pres_lds_stage(mhh_pres_plan* P, const mhh_grid* g, const mhh_fi
         MHH_REQUIRE(f && f->p && f->ut && f->vt && f->wt, "null field");
 #define M(TF, N) else if (nx == N) hipLaunchKernelGGL((lds_fft::pres_ifftx_out_kernel<TF, LDS_RG, (2 << N), N>), xgrid, dim3(P->itot), lds_bytes_x(P, 9), st, a);
 #define CALL(TF) [&]{ lds_fft::PresLdsOut<TF> a{make_grid<TF>(g), static_cast<const C2<TF>*>(P->spec), static_cast<const C2<TF>*>(P->tx), \
-                          mp<TF>(f->p), mp<TF>(f->ut), mp<TF>(f->vt), mp<TF>(f->wt), nx, kc}; \
+                          mp<TF>(f->p), mp<TF>(f->ut), mp<TF>(f->vt), mp<TF>(f->wt), nx, kc, 0, P->ktot, P->jtot, {}}; \
                       if (P->itot <= LDS_XS) hipLaunchKernelGGL((lds_fft::pres_ifftx_out_kernel<TF, LDS_RG, LDS_XS, 0>), xgrid, dim3(P->itot), lds_bytes_x(P, 9), st, a); \
                       MHH_FOR_NX_T(M, TF) return MHH_OK; }()
         if (int e = MHH_DISPATCH(g, CALL)) return e;
@@ -1044,6 +1044,94 @@ MHH_API int mhh_pres_lds_stage(mhh_pres_plan* P, const mhh_grid* g, const mhh_fi
     MHH_LAUNCH_CHECK();
     return MHH_OK;
 }
+// ---- the x stages for a slab rank (k_slab.hip): the same kernels on the rank's own rows, reading / writing the all-to-all
+// buffers of the x <-> y transposes directly (pres_lds.h, LdsSlab). Internal to the library (pres_lds_slab.h).
+namespace mhh
+{
+template<class TF>
+static int lds_slab_kernels_ready(int itot, bool& usable)
+{
+    const int nx = ilog2(itot/2);
+    const void* k[2] = {nullptr, nullptr};
+    if (itot <= LDS_XS) { k[0] = reinterpret_cast<const void*>(&lds_fft::pres_in_fftx_kernel<TF, LDS_RG, LDS_XS, 0, true>); k[1] = reinterpret_cast<const void*>(&lds_fft::pres_ifftx_out_kernel<TF, LDS_RG, LDS_XS, 0, true>); }
+#define M(N) if (nx == N) { k[0] = reinterpret_cast<const void*>(&lds_fft::pres_in_fftx_kernel<TF, LDS_RG, (2 << N), N, true>); k[1] = reinterpret_cast<const void*>(&lds_fft::pres_ifftx_out_kernel<TF, LDS_RG, (2 << N), N, true>); }
+    MHH_FOR_NX(M)
+#undef M
+    usable = true;
+    for (int n=0; n<2; ++n)
+    {
+        if (!k[n]) { usable = false; return MHH_OK; }
+        bool u = false;
+        if (int e = lds_kernel_ready(k[n], u)) return e;
+        usable = usable && u;
+    }
+    return MHH_OK;
+}
+static size_t lds_slab_bytes_x(int itot, size_t esz, int rows) { return ((size_t)rows*(itot/2 + 2) + itot) * 2*esz + (rows == 9 ? (size_t)8*itot*esz : 0); }
+// 1 if a rank of this grid can run the x stages in LDS: power-of-two itot with an instantiation, rows in whole strips of eight
+int lds_slab_usable(const mhh_grid* g)
+{
+    if (!(is_pow2(g->itot) && g->itot >= 16 && g->itot <= 1024 && g->jmax % 8 == 0 && g->jmax >= 8)) return 0;
+    if (lds_slab_bytes_x(g->itot, g->dtype == MHH_F64 ? 8 : 4, 9) > 160*1024 || g->igc > g->itot) return 0;
+    if ((long long)g->icells*g->jcells*g->kcells >= (1ll << 31)) return 0;
+    bool usable = false;
+    const int e = (g->dtype == MHH_F64) ? lds_slab_kernels_ready<double>(g->itot, usable) : lds_slab_kernels_ready<float>(g->itot, usable);
+    return (e == MHH_OK && usable) ? 1 : 0;
+}
+// exp(-2 pi i m / itot), m < itot, on the device (the caller frees it)
+int lds_slab_twiddles(const mhh_grid* g, void** tx)
+{
+    const double pi = std::acos(-1.);
+    const int n = g->itot;
+    auto fill = [&](auto* t) { for (int m=0; m<n; ++m) { t[2*m] = std::cos(2.*pi*m/n); t[2*m+1] = -std::sin(2.*pi*m/n); }
+                               t[0] = 1; t[1] = 0; t[n] = -1; t[n+1] = 0; if (n >= 4) { t[n/2] = 0; t[n/2+1] = -1; t[3*n/2] = 0; t[3*n/2+1] = 1; } };
+    if (g->dtype == MHH_F64) { std::vector<double> t(2*(size_t)n); fill(t.data()); return upload(tx, t); }
+    std::vector<float> t(2*(size_t)n); fill(t.data()); return upload(tx, t);
+}
+static int lds_slab_kc(const mhh_grid* g, int nlev)
+{
+    const char* e = getenv("MHH_PRES_LDS_KC");
+    int kc = e ? atoi(e) : (int)(((long long)nlev * (g->jmax/8)) / 2048);
+    if (!e) kc = kc < 4 ? 4 : (kc > 32 ? 32 : kc);
+    return kc < 1 ? 1 : (kc > nlev ? nlev : kc);
+}
+// Pres_2::input + the transform along x of the levels [kbeg, kend) into the send buffer of the x -> y transpose
+int lds_slab_stage_in(const mhh_grid* g, const mhh_fields* f, double dt, void* xbuf, const void* tx, int nxb, int npy, int ks, int kbeg, int kend, hipStream_t st)
+{
+    if (int e = pres_input_halos(g, 2, f, st)) return e;
+    const int nx = ilog2(g->itot/2), kc = lds_slab_kc(g, kend - kbeg);
+    const dim3 xgrid((unsigned)(g->jmax/8) * (unsigned)((kend - kbeg + kc-1)/kc));
+    const size_t lds = lds_slab_bytes_x(g->itot, g->dtype == MHH_F64 ? 8 : 4, 8);
+#define M(TF, N) else if (nx == N) hipLaunchKernelGGL((lds_fft::pres_in_fftx_kernel<TF, LDS_RG, (2 << N), N, true>), xgrid, dim3(g->itot), lds, st, a);
+#define CALL(TF) [&]{ lds_fft::PresLdsIn<TF> a{make_grid<TF>(g), cp<TF>(f->u), cp<TF>(f->v), cp<TF>(f->w), cp<TF>(f->ut), cp<TF>(f->vt), cp<TF>(f->wt), \
+                          cp<TF>(f->rhoref), cp<TF>(f->rhorefh), TF(1.)/TF(dt), static_cast<C2<TF>*>(xbuf), static_cast<const C2<TF>*>(tx), nx, kc, kbeg, kend, g->jmax, {nxb, npy, ks}}; \
+                      if (g->itot <= LDS_XS) hipLaunchKernelGGL((lds_fft::pres_in_fftx_kernel<TF, LDS_RG, LDS_XS, 0, true>), xgrid, dim3(g->itot), lds, st, a); \
+                      MHH_FOR_NX_T(M, TF) return MHH_OK; }()
+    if (int e = MHH_DISPATCH(g, CALL)) return e;
+#undef CALL
+#undef M
+    MHH_LAUNCH_CHECK();
+    return MHH_OK;
+}
+// the transform back along x of the levels [kbeg, kend) from the receive buffer of the y -> x transpose + p + Pres_2::output
+int lds_slab_stage_out(const mhh_grid* g, const mhh_fields* f, const void* xbuf, const void* tx, int nxb, int npy, int ks, int kbeg, int kend, hipStream_t st)
+{
+    const int nx = ilog2(g->itot/2), kc = lds_slab_kc(g, kend - kbeg);
+    const dim3 xgrid((unsigned)(g->jmax/8) * (unsigned)((kend - kbeg + kc-1)/kc));
+    const size_t lds = lds_slab_bytes_x(g->itot, g->dtype == MHH_F64 ? 8 : 4, 9);
+#define M(TF, N) else if (nx == N) hipLaunchKernelGGL((lds_fft::pres_ifftx_out_kernel<TF, LDS_RG, (2 << N), N, true>), xgrid, dim3(g->itot), lds, st, a);
+#define CALL(TF) [&]{ lds_fft::PresLdsOut<TF> a{make_grid<TF>(g), static_cast<const C2<TF>*>(xbuf), static_cast<const C2<TF>*>(tx), \
+                          mp<TF>(f->p), mp<TF>(f->ut), mp<TF>(f->vt), mp<TF>(f->wt), nx, kc, kbeg, kend, g->jmax, {nxb, npy, ks}}; \
+                      if (g->itot <= LDS_XS) hipLaunchKernelGGL((lds_fft::pres_ifftx_out_kernel<TF, LDS_RG, LDS_XS, 0, true>), xgrid, dim3(g->itot), lds, st, a); \
+                      MHH_FOR_NX_T(M, TF) return MHH_OK; }()
+    if (int e = MHH_DISPATCH(g, CALL)) return e;
+#undef CALL
+#undef M
+    MHH_LAUNCH_CHECK();
+    return MHH_OK;
+}
+} // namespace mhh
+
 // 1 if the plan can run the LDS-transform form (mhh_pres_exec takes it by itself on large grids, see there)
 MHH_API int mhh_pres_plan_has_lds_form(const mhh_pres_plan* P) { return (P && P->lds_ok) ? 1 : 0; }
 // the spectral array between the stages (tests): S[k][kx][j], complex

@@ -10,6 +10,7 @@
 #include <rocfft/rocfft.h>
 #include "fft_lifetime.h"
 #include "k_common.h"
+#include "pres_lds_slab.h"
 
 using namespace mhh;
 
@@ -110,6 +111,8 @@ struct mhh_pres_slab_plan
     rocfft_plan cfx = nullptr, cbx = nullptr, cfy = nullptr, cby = nullptr;
     rocfft_execution_info info = nullptr;
     void* wb = nullptr; size_t wbs = 0, wb_cap = 0;
+    // the x stages with the transforms in LDS (pres_lds.h, pres_lds_slab.h): twiddles exp(-2 pi i m / itot); null = not available
+    void* tx_lds = nullptr;
 };
 
 template<class TF>
@@ -164,6 +167,7 @@ static int plan1d(rocfft_plan* plan, rocfft_transform_type type, rocfft_result_p
 
 MHH_API void mhh_pres_slab_plan_destroy(mhh_pres_slab_plan* P)
 {
+    if (P && P->tx_lds) { (void)hipFree(P->tx_lds); P->tx_lds = nullptr; }
     if (!P) return;
     for (rocfft_plan p : {P->fx, P->bx, P->fy, P->by, P->cfx, P->cbx, P->cfy, P->cby}) if (p) rocfft_plan_destroy(p);
     if (P->info) rocfft_execution_info_destroy(P->info);
@@ -205,6 +209,7 @@ MHH_API int mhh_pres_slab_plan_create(const mhh_grid* g, const void* host_dz, co
         }
     }
     if (!e) e = slab_factor(P);
+    if (!e && lds_slab_usable(g)) e = lds_slab_twiddles(g, &P->tx_lds);      // the x stages with the transforms in LDS
     if (e) { mhh_pres_slab_plan_destroy(P); return e; }
     *out = P;
     return MHH_OK;
@@ -732,6 +737,33 @@ MHH_API int mhh_pres_bwd_x_chunk(mhh_pres_slab_plan* P, const mhh_grid* g, void*
     void* in[1] = {static_cast<char*>(P->specx) + sl.sx*2*P->esz}; void* out[1] = {static_cast<char*>(P->packed) + sl.pk*P->esz};
     MHH_FFT_TRY(rocfft_execute(P->cbx, in, out, P->info));
     return MHH_OK;
+}
+// ---- the x stages with the transforms in LDS (pres_lds.h): input + x transform WRITING the send buffer of the x -> y transpose,
+// x transform + p + output READING the receive buffer of the y -> x transpose -- two kernels and four array passes per rank where
+// the staged form has input | x r2c | pack and unpack | x c2r | unpack + output (six kernels, eleven passes). The y stage between
+// the transposes is unchanged. c = k-slice (0 with unsliced transposes): the kernels work the levels of that slice only.
+MHH_API int mhh_pres_slab_has_lds(const mhh_pres_slab_plan* P)
+{
+    const char* e = getenv("MHH_PRES_SLAB_LDS");          // "0": the staged x stages (A/B runs, tests of both forms)
+    return (P && P->tx_lds && !(e && !strcmp(e, "0"))) ? 1 : 0;
+}
+MHH_API int mhh_pres_slab_lds_fwd(mhh_pres_slab_plan* P, const mhh_grid* g, const mhh_fields* f, double dt, void* sendbuf, int c, void* stream)
+{
+    if (int e = slab_match(P, g)) return e;
+    MHH_REQUIRE(P->tx_lds != nullptr, "this plan has no LDS form of the x stages (power-of-two itot, jmax a multiple of 8)");
+    MHH_REQUIRE(f && f->u && f->v && f->w && f->ut && f->vt && f->wt && f->rhoref && f->rhorefh && sendbuf, "null field");
+    MHH_REQUIRE(dt > 0. && c >= 0 && c < P->nchunks, "dt, k-slice");
+    const int ks = P->ktot / P->nchunks;
+    return lds_slab_stage_in(g, f, dt, sendbuf, P->tx_lds, P->nxb, P->npy, ks, c*ks, (c+1)*ks, as_stream(stream));
+}
+MHH_API int mhh_pres_slab_lds_bwd(mhh_pres_slab_plan* P, const mhh_grid* g, const void* recvbuf, const mhh_fields* f, int c, void* stream)
+{
+    if (int e = slab_match(P, g)) return e;
+    MHH_REQUIRE(P->tx_lds != nullptr, "this plan has no LDS form of the x stages (power-of-two itot, jmax a multiple of 8)");
+    MHH_REQUIRE(f && f->p && f->ut && f->vt && f->wt && recvbuf, "null field");
+    MHH_REQUIRE(c >= 0 && c < P->nchunks, "k-slice");
+    const int ks = P->ktot / P->nchunks;
+    return lds_slab_stage_out(g, f, recvbuf, P->tx_lds, P->nxb, P->npy, ks, c*ks, (c+1)*ks, as_stream(stream));
 }
 // all slices back: unpack + Pres_2::output in one kernel (the tail of mhh_pres_bwd_x_unpack_output)
 MHH_API int mhh_pres_unpack_output_slab(mhh_pres_slab_plan* P, const mhh_grid* g, const mhh_fields* f, void* stream)

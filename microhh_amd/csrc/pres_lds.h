@@ -201,6 +201,18 @@ __device__ __forceinline__ void lds_strip_of_block(int nstrips, int& strip, int&
     else { chunk = (int)(id / (unsigned)nstrips); strip = (int)(id - (unsigned)chunk*(unsigned)nstrips); }
 }
 
+// Slab-decomposed grids (npx = 1, npy = N; k_slab.hip): the x-stage kernels work on the rank's own rows and talk to the
+// all-to-all buffers of the x <-> y transpose directly (src/transpose.cxx:170-219): layout [slice][peer q][k in slice][row][kxl],
+// kx = q*nxb + kxl, the itot/2 + 1 modes unpacked (the Nyquist mode in a column of its own, as the y stage of k_slab.hip expects)
+// and padded with zeros to npy*nxb columns. A thread then handles one MODE of a row (consecutive threads = consecutive modes: runs
+// of nxb complex numbers per peer) instead of one row of a mode.
+struct LdsSlab { int nxb, npy, ks; };                    // modes per peer, peers, levels per slice
+template<class TF> __device__ __forceinline__ size_t lds_xbuf_index(const LdsSlab& sl, int k, int kx, int row, int nrows)
+{
+    const int c = k / sl.ks, kk = k - c*sl.ks, q = kx / sl.nxb, kxl = kx - q*sl.nxb;
+    return ((((size_t)c*sl.npy + q)*sl.ks + kk)*nrows + row)*sl.nxb + kxl;
+}
+
 // ======================================================================================================================
 // (1) Pres_2::input + the transform along x. Block = 8 rows j0..j0+7, marching up through KC levels; thread = column i.
 // ======================================================================================================================
@@ -213,8 +225,11 @@ struct PresLdsIn
     C2<TF>* S; const C2<TF>* Tx;      // Tx[m] = exp(-2 pi i m / itot), m < itot
     int nx;                           // log2(itot/2)
     int kc;                           // levels per block
+    int kbeg, kend;                   // the levels of this launch (a k-slice of the sliced transposes; 0, kmax otherwise)
+    int nrows;                        // rows worked: jtot, or the rank's jmax
+    LdsSlab sl;                       // SLAB only
 };
-template<class TF, int RG, int BT, int NX>
+template<class TF, int RG, int BT, int NX, bool SLAB = false>
 __global__ void __launch_bounds__(BT, (BT >= 128 ? 4 : 1)) pres_in_fftx_kernel(const PresLdsIn<TF> a)
 {
     HIP_DYNAMIC_SHARED(LdsUnit, lds_raw);
@@ -224,8 +239,8 @@ __global__ void __launch_bounds__(BT, (BT >= 128 ? 4 : 1)) pres_in_fftx_kernel(c
     C2<TF>* T = D + 8*rp;
     const int tid = threadIdx.x;                   // blockDim.x == itot
     T[tid] = a.Tx[tid];
-    int strip, chunk; lds_strip_of_block(jtot >> 3, strip, chunk);
-    const int j0 = strip*8, k0 = chunk*a.kc, k1 = (k0 + a.kc < g.kmax) ? k0 + a.kc : g.kmax;
+    int strip, chunk; lds_strip_of_block(a.nrows >> 3, strip, chunk);
+    const int j0 = strip*8, k0 = a.kbeg + chunk*a.kc, k1 = (k0 + a.kc < a.kend) ? k0 + a.kc : a.kend;
     const int jj = g.icells, kk = g.ijcells;
     const int c0 = (tid + g.igc) + (j0 + g.jgc)*jj;
     const int team = nh >> 3, slot = tid / team, l = tid - slot*team;     // the transform this thread works on in the passes
@@ -276,15 +291,34 @@ __global__ void __launch_bounds__(BT, (BT >= 128 ? 4 : 1)) pres_in_fftx_kernel(c
         lds_barrier();
         // real-to-complex: X[kx] = E + exp(-2 pi i kx / itot) O from Z[kx] and Z[nh - kx]; one (kx, row) element per thread and turn,
         // rows fastest: eight neighbouring threads write one 128-byte (fp64) piece of S[k][kx][j0..j0+7]
-        for (int e=(int)tl; e<8*nh; e+=itot)
+        if constexpr (!SLAB)
         {
-            const int kx = e >> 3, r = e & 7;
-            const C2<TF> za = D[r*rp + lds_slot<TF>(kx)], zb = D[r*rp + lds_slot<TF>((nh - kx) & (nh-1))];
-            const C2<TF> ev{TF(0.5)*(za.x + zb.x), TF(0.5)*(za.y - zb.y)};         // (Za + conj Zb) / 2
-            const C2<TF> od{TF(0.5)*(za.y + zb.y), TF(0.5)*(zb.x - za.x)};         // (Za - conj Zb) / (2 i)
-            C2<TF> x = ev + mul_tw<-1>(od, T[kx]);
-            if (kx == 0) x = C2<TF>{za.x + za.y, za.x - za.y};                      // (X_0, X_nyq): both real, one column
-            a.S[((size_t)k*nh + kx)*jtot + j0 + r] = x;
+            for (int e=(int)tl; e<8*nh; e+=itot)
+            {
+                const int kx = e >> 3, r = e & 7;
+                const C2<TF> za = D[r*rp + lds_slot<TF>(kx)], zb = D[r*rp + lds_slot<TF>((nh - kx) & (nh-1))];
+                const C2<TF> ev{TF(0.5)*(za.x + zb.x), TF(0.5)*(za.y - zb.y)};         // (Za + conj Zb) / 2
+                const C2<TF> od{TF(0.5)*(za.y + zb.y), TF(0.5)*(zb.x - za.x)};         // (Za - conj Zb) / (2 i)
+                C2<TF> x = ev + mul_tw<-1>(od, T[kx]);
+                if (kx == 0) x = C2<TF>{za.x + za.y, za.x - za.y};                      // (X_0, X_nyq): both real, one column
+                a.S[((size_t)k*nh + kx)*jtot + j0 + r] = x;
+            }
+        }
+        else
+        {
+            // modes fastest: thread kx <= nh of every row; kx = 0 and kx = nh (Nyquist) are real
+            for (int e=(int)tl; e<8*(nh + 1); e+=itot)
+            {
+                const int r = e / (nh + 1), kx = e - r*(nh + 1);
+                const int ka = kx & (nh-1);
+                const C2<TF> za = D[r*rp + lds_slot<TF>(ka)], zb = D[r*rp + lds_slot<TF>((nh - ka) & (nh-1))];
+                const C2<TF> ev{TF(0.5)*(za.x + zb.x), TF(0.5)*(za.y - zb.y)};
+                const C2<TF> od{TF(0.5)*(za.y + zb.y), TF(0.5)*(zb.x - za.x)};
+                C2<TF> x = ev + mul_tw<-1>(od, T[ka]);
+                if (kx == 0) x = C2<TF>{za.x + za.y, TF(0)};
+                if (kx == nh) x = C2<TF>{za.x - za.y, TF(0)};
+                a.S[lds_xbuf_index<TF>(a.sl, k, kx, j0 + r, a.nrows)] = x;
+            }
         }
         lds_barrier();
     }
@@ -537,8 +571,13 @@ struct PresLdsOut
     const C2<TF>* S; const C2<TF>* Tx;
     TF* p; TF* ut; TF* vt; TF* wt;
     int nx, kc;
+    int kbeg, kend;                   // the levels of this launch
+    int nrows;                        // rows worked: jtot, or the rank's jmax
+    LdsSlab sl;                       // SLAB only
 };
-template<class TF, int RG, int BT, int NX>
+// SLAB: rows are the rank's own; the row south of the first strip belongs to the south neighbour, so vt of the rank's southernmost
+// row is left to mhh_pres_output_south_row (after the one-row halo of p), and p gets its x halo only (the y halo is the exchange's)
+template<class TF, int RG, int BT, int NX, bool SLAB = false>
 __global__ void __launch_bounds__(BT, (BT >= 128 ? 4 : 1)) pres_ifftx_out_kernel(const PresLdsOut<TF> a)
 {
     HIP_DYNAMIC_SHARED(LdsUnit, lds_raw);
@@ -548,14 +587,15 @@ __global__ void __launch_bounds__(BT, (BT >= 128 ? 4 : 1)) pres_ifftx_out_kernel
     C2<TF>* T = D + 9*rp;
     const int tid = threadIdx.x;                   // blockDim.x == itot
     T[tid] = a.Tx[tid];
-    int strip, chunk; lds_strip_of_block(jtot >> 3, strip, chunk);
-    const int j0 = strip*8, k0 = chunk*a.kc, k1 = (k0 + a.kc < g.kmax) ? k0 + a.kc : g.kmax;
+    int strip, chunk; lds_strip_of_block(a.nrows >> 3, strip, chunk);
+    const int j0 = strip*8, k0 = a.kbeg + chunk*a.kc, k1 = (k0 + a.kc < a.kend) ? k0 + a.kc : a.kend;
     const int jj = g.icells, kk = g.ijcells;
     const int team = nh >> 3, slot = tid / team, l = tid - slot*team;
     const bool active = slot < 9;
+    const bool has_south = !SLAB || j0 > 0;                            // row j0-1 is at hand
     const TF* Dr = reinterpret_cast<const TF*>(D);
     const TF nrm = (TF(1) / TF(jtot)) * (TF(1) / TF(itot));           // both powers of two: exact
-    const int jsouth = (j0 + jtot - 1) & (jtot - 1);
+    const int jsouth = SLAB ? j0 - 1 : ((j0 + jtot - 1) & (jtot - 1));
     const int iw = (tid + itot - 1) & (itot - 1);
     // p of the level below, eight rows of this thread's column: in LDS rather than in sixteen registers (see the note on spills below)
     TF* below = reinterpret_cast<TF*>(T + itot) + tid;               // below[r*itot]
@@ -570,11 +610,28 @@ __global__ void __launch_bounds__(BT, (BT >= 128 ? 4 : 1)) pres_ifftx_out_kernel
         // cycles). An opaque copy of the thread index per level keeps that arithmetic inside the level.
         unsigned tl = (unsigned)tid; keep_vgpr(tl);
         // spectral rows -> LDS (columns 0 .. nh-1, column 0 = (X_0, X_nyq); rows fastest in memory)
-        for (int e=(int)tl; e<9*nh; e+=itot)
+        if constexpr (!SLAB)
         {
-            const int kx = e / 9, r = e - 9*kx;
-            const int j = (r == 0) ? jsouth : j0 + r - 1;
-            D[r*rp + lds_slot<TF>(kx)] = a.S[((size_t)k*nh + kx)*jtot + j];
+            for (int e=(int)tl; e<9*nh; e+=itot)
+            {
+                const int kx = e / 9, r = e - 9*kx;
+                const int j = (r == 0) ? jsouth : j0 + r - 1;
+                D[r*rp + lds_slot<TF>(kx)] = a.S[((size_t)k*nh + kx)*jtot + j];
+            }
+        }
+        else
+        {
+            TF* Dw = reinterpret_cast<TF*>(D);
+            for (int e=(int)tl; e<9*(nh + 1); e+=itot)
+            {
+                const int r = e / (nh + 1), kx = e - r*(nh + 1);
+                const int j = j0 + r - 1;
+                if (r == 0 && !has_south) continue;                      // (that row of LDS stays undefined; its p is never used)
+                const C2<TF> x = a.S[lds_xbuf_index<TF>(a.sl, k, kx, j, a.nrows)];
+                if (kx == 0)       Dw[2*(r*rp + lds_slot<TF>(0))] = x.x;          // column 0 = (X_0, X_nyq)
+                else if (kx == nh) Dw[2*(r*rp + lds_slot<TF>(0)) + 1] = x.x;
+                else               D[r*rp + lds_slot<TF>(kx)] = x;
+            }
         }
         lds_barrier();
         // complex-to-real: Z[kx] = (Xa + conj Xb) + i (Xa - conj Xb) exp(+2 pi i kx / itot), Xb = X[nh - kx]; pairs (kx, nh - kx) in place
@@ -622,7 +679,7 @@ __global__ void __launch_bounds__(BT, (BT >= 128 ? 4 : 1)) pres_ifftx_out_kernel
                     const int cr = c + r*jj;
                     const TF pb = (k == 0) ? pc : below[r*itot];                          // p[kstart-1] = p[kstart]
                     a.ut[cr] = tu[q] - (pc - pw) * g.dxi_t;
-                    a.vt[cr] = tv[q] - (pc - ps) * g.dyi_t;
+                    if (has_south || r > 0) a.vt[cr] = tv[q] - (pc - ps) * g.dyi_t;
                     a.wt[cr] = tw[q] - (pc - pb) * dzhi_k;
                     // p: the cell, its images in the periodic halo, and the ghost level below the first one
                     const int js = j0 + r;
@@ -634,6 +691,7 @@ __global__ void __launch_bounds__(BT, (BT >= 128 ? 4 : 1)) pres_ifftx_out_kernel
                         {
                             int off;
                             if (rowsel == 0) off = 0;
+                            else if (SLAB) continue;                                                        // the y halo is the neighbours'
                             else if (rowsel == 1) { if (js < jtot - g.jgc) continue; off = -jtot*jj; }     // row js - jtot: the south halo
                             else                  { if (js >= g.jgc) continue;       off =  jtot*jj; }     // row js + jtot: the north halo
                             a.p[cl + off] = pc;

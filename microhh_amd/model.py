@@ -403,15 +403,28 @@ class HotPath:
         lib, st = self.lib, self.stream
         if self.slim: self.halo([self.vt], rows_south=1, rows_north=0)      # only vt[j+1] at the north edge is read (pres_2.cxx:181,193)
         else:         self.halo([self.vt])
+        F = C.byref(self.fields)
+        # x stages with the transforms in LDS where the plan has them (needs the slim halos: p's y halo is the one row): input + x
+        # transform write the send buffer, x transform + p + output read the receive buffer -- no packed array, no pack / unpack
+        lds_x = self.slim and lib.mhh_pres_slab_has_lds(self.plan) == 1
         packed = lib.mhh_pres_slab_packed(self.plan)
-        self._ok(lib.mhh_pres_input_packed(self.G, 2, C.byref(self.fields), self.dt, packed, st))
+        if not lds_x:
+            self._ok(lib.mhh_pres_input_packed(self.G, 2, F, self.dt, packed, st))
         if self.pres_chunks > 1:
-            self._pres_sliced(packed)
+            self._pres_sliced(packed, lds_x)
             return
-        self._ok(lib.mhh_pres_fwd_x_pack(self.plan, self.G, packed, self.xsend.data_ptr(), st))
+        if lds_x:
+            self._ok(lib.mhh_pres_slab_lds_fwd(self.plan, self.G, F, self.dt, self.xsend.data_ptr(), 0, st))
+        else:
+            self._ok(lib.mhh_pres_fwd_x_pack(self.plan, self.G, packed, self.xsend.data_ptr(), st))
         self._transpose()                                                    # Transpose::exec_xy
         self._ok(lib.mhh_pres_fwd_y_solve_bwd_y(self.plan, self.G, self.xrecv.data_ptr(), self.xsend.data_ptr(), self.stream))
         self._transpose()                                                    # Transpose::exec_yx
+        if lds_x:
+            self._ok(lib.mhh_pres_slab_lds_bwd(self.plan, self.G, self.xrecv.data_ptr(), F, 0, self.stream))
+            self.halo([self.p], rows_south=0, rows_north=1)
+            self._ok(lib.mhh_pres_output_south_row(self.G, F, self.stream))
+            return
         if self.slim:
             # unpack + Pres_2::output in one kernel for everything but vt on the southernmost row, whose p[j-1] arrives with the
             # one-row halo of p (pres_2.cxx:383-385)
@@ -423,7 +436,7 @@ class HotPath:
             self.halo([self.p])
             self._ok(lib.mhh_pres_output_order(self.G, 2, C.byref(self.fields), self.stream))
 
-    def _pres_sliced(self, packed):
+    def _pres_sliced(self, packed, lds_x=False):
         """Pres_2::exec after the input stage, in k-slices: per slice x transform + pack, all-to-all on the exchange stream while
         the next slice is transformed, y transform as each slice arrives; Thomas sweeps over all levels; the same on the way back.
         Same kernels per plane as the unsliced path (tests/test_slab_gloo.py compares the two)."""
@@ -452,7 +465,8 @@ class HotPath:
                 done.record(self._comm_stream)
 
         for c in range(n):
-            self._ok(lib.mhh_pres_fwd_x_pack_chunk(self.plan, self.G, packed, self.xsend.data_ptr(), c, self.stream))
+            if lds_x: self._ok(lib.mhh_pres_slab_lds_fwd(self.plan, self.G, F, self.dt, self.xsend.data_ptr(), c, self.stream))
+            else:     self._ok(lib.mhh_pres_fwd_x_pack_chunk(self.plan, self.G, packed, self.xsend.data_ptr(), c, self.stream))
             exchange(c, *( (self._sl_ev[0][c], self._sl_ev[1][c]) if two_streams else (None, None) ))
         for c in range(n):
             if two_streams:
@@ -465,8 +479,10 @@ class HotPath:
         for c in range(n):
             if two_streams:
                 main.wait_event(self._sl_ev[3][c])
-            self._ok(lib.mhh_pres_bwd_x_chunk(self.plan, self.G, self.xrecv.data_ptr(), c, self.stream))
-        self._ok(lib.mhh_pres_unpack_output_slab(self.plan, self.G, F, self.stream))
+            if lds_x: self._ok(lib.mhh_pres_slab_lds_bwd(self.plan, self.G, self.xrecv.data_ptr(), F, c, self.stream))
+            else:     self._ok(lib.mhh_pres_bwd_x_chunk(self.plan, self.G, self.xrecv.data_ptr(), c, self.stream))
+        if not lds_x:
+            self._ok(lib.mhh_pres_unpack_output_slab(self.plan, self.G, F, self.stream))
         self.halo([self.p], rows_south=0, rows_north=1)
         self._ok(lib.mhh_pres_output_south_row(self.G, F, self.stream))
 

@@ -41,9 +41,12 @@ res = {
  "bwd_x_unpack_output (fused)": timeit(lambda: lib.mhh_pres_bwd_x_unpack_output(hp.plan, hp.G, hp.xrecv.data_ptr(), f, st)),
  "halo(p, 1 row north)": timeit(lambda: hp.halo([hp.p], rows_south=0, rows_north=1)),
  "pres_output south row": timeit(lambda: lib.mhh_pres_output_south_row(hp.G, f, st)),
+ "LDS x stage 1: input + x transform -> send buffer": timeit(lambda: lib.mhh_pres_slab_lds_fwd(hp.plan, hp.G, f, 1.0, hp.xsend.data_ptr(), 0, st)) if lib.mhh_pres_slab_has_lds(hp.plan) and hp.pres_chunks == 1 else float("nan"),
+ "LDS x stage 3: receive buffer -> x transform + p + output": timeit(lambda: lib.mhh_pres_slab_lds_bwd(hp.plan, hp.G, hp.xrecv.data_ptr(), f, 0, st)) if lib.mhh_pres_slab_has_lds(hp.plan) and hp.pres_chunks == 1 else float("nan"),
  "(two-kernel form) bwd_x_unpack": timeit(lambda: lib.mhh_pres_bwd_x_unpack(hp.plan, hp.G, hp.xrecv.data_ptr(), f, st)),
  "(two-kernel form) pres_output": timeit(lambda: lib.mhh_pres_output_order(hp.G, 2, f, st)),
  "full step (no comm)": timeit(hp.step),
 }
-for k, v in res.items(): print("%-32s %8.3f ms" % (k, v))
+for k, v in res.items(): print("%-58s %8.3f ms" % (k, v))
+print("x stages in LDS: %s; k-slices of the transposes: %d" % ("yes" if lib.mhh_pres_slab_has_lds(hp.plan) else "no (MHH_PRES_SLAB_LDS=0 or no such form)", hp.pres_chunks))
 print("all-to-all volume per rank per direction: %.1f MB" % (hp.xsend.numel()*8/1e6))

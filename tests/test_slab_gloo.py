@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import backends as B  # noqa: E402
 from microhh_amd.model import HotPath, synthetic_global  # noqa: E402
 
-GRID = (16, 24, 10)
+GRID = (16, 32, 10)        # jmax = 16 / 8 rows per rank: whole strips of eight, so the slim-halo runs take the LDS x stages of the pressure solve
 
 
 def _interior(hp, t):
@@ -45,14 +45,16 @@ def _run(hp, out, overlapped=False):
     out["cfl"] = np.array(hp.cfl(0.5))
 
 
-def _worker(rank, world, port, tmp, slim):
+def _worker(rank, world, port, tmp, slim, lds_x=True):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["MHH_PRES_SLAB_LDS"] = "1" if lds_x else "0"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         lib = B.get("emul").lib
         hp = HotPath("drycblles", *GRID, device="cpu", lib=lib, npy=world, rank=rank, global_init=synthetic_global("drycblles", *GRID),
                      slim_halos=slim, overlap=(slim and world == 2))
         assert hp.evisc_local_ghosts == slim
+        assert lib.mhh_pres_slab_has_lds(hp.plan) == (1 if lds_x else 0)
         out = {}
         _run(hp, out, overlapped=(slim and world == 2))
         np.savez(os.path.join(tmp, "rank%d.npz" % rank), **out)
@@ -61,17 +63,19 @@ def _worker(rank, world, port, tmp, slim):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,slim", [(2, True), (4, True), (2, False)], ids=["2-slim", "4-slim", "2-full-halos"])
-def test_slab_matches_single_rank(world, slim):
+@pytest.mark.parametrize("world,slim,lds_x", [(2, True, True), (4, True, True), (2, False, True), (2, True, False)], ids=["2-slim", "4-slim", "2-full-halos", "2-slim-staged-x"])
+def test_slab_matches_single_rank(world, slim, lds_x):
     """slim: one-row vt / p exchanges and evisc evaluated on the adjacent ghost rows; full: the reference's jgc-row
-    exchanges of vt, p and evisc. Both must reproduce the single-rank bits."""
+    exchanges of vt, p and evisc. Both must reproduce the single-rank bits. The slim runs solve the pressure with the x stages in
+    LDS writing / reading the all-to-all buffers (mhh_pres_slab_lds_fwd / _bwd), "staged-x" and the full-halo run with the rocFFT
+    x stages (input | x transform | pack and the reverse)."""
     lib = B.get("emul").lib
     ref = {}
     hp = HotPath("drycblles", *GRID, device="cpu", lib=lib, global_init=synthetic_global("drycblles", *GRID))
     _run(hp, ref)
     hp.close()
     with tempfile.TemporaryDirectory() as tmp:
-        mp.spawn(_worker, args=(world, 29500 + world + 7*int(slim) + os.getpid() % 1000, tmp, slim), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, 29500 + world + 7*int(slim) + 13*int(lds_x) + os.getpid() % 1000, tmp, slim, lds_x), nprocs=world, join=True)
         parts = [np.load(os.path.join(tmp, "rank%d.npz" % r)) for r in range(world)]
         for key in ("evisc", "rhs_ut", "rhs_vt", "rhs_wt", "rhs_st"):
             got = np.concatenate([p[key] for p in parts], axis=1)
