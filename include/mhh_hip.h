@@ -227,6 +227,7 @@ int mhh_diff_exec_viscosity(const mhh_grid* g, int scheme, const mhh_fields* f, 
  * all rows): lets the slab driver evaluate the rows that need no north-south halo while the halos travel. */
 int mhh_diff_exec_viscosity_rows(const mhh_grid* g, int scheme, const mhh_fields* f, const mhh_diff_params* p,
                                  int j0, int j1, void* stream);
+int mhh_diff_exec_viscosity_rows2(const mhh_grid* g, int scheme, const mhh_fields* f, const mhh_diff_params* p, int j0, int j1, int j2, int j3, void* stream);
 /* diagnostic: launches of the k-marching form of exec_viscosity so far (it needs 16-byte aligned rows; other layouts
  * take the one-thread-per-cell kernel, same bits) */
 unsigned long long mhh_stat_visc_march_launches(void);
@@ -250,6 +251,8 @@ int mhh_rhs_exec(const mhh_grid* g, int advec_scheme, int diff_scheme, const mhh
  * scalar; same bits as the whole-slab call on those rows */
 int mhh_rhs_exec_rows(const mhh_grid* g, int advec_scheme, int diff_scheme, const mhh_fields* f,
                       const mhh_diff_params* p, int j0, int j1, void* stream);
+/* the same over TWO disjoint, ordered row ranges in one launch (a slab's two edge strips once its north-south halos are in) */
+int mhh_rhs_exec_rows2(const mhh_grid* g, int advec_scheme, int diff_scheme, const mhh_fields* f, const mhh_diff_params* p, int j0, int j1, int j2, int j3, void* stream);
 
 /* ---- Pressure ----------------------------------------------------------------------------
  * Plan object = Pres_2 / Pres_4 private state: bmati/bmatj, a/c (m1..m7), rocFFT plans,

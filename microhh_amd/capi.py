@@ -55,7 +55,9 @@ SIGNATURES = {
     "mhh_advec_exec": (ci, [GP, ci, FP, vp]),
     "mhh_stat_visc_march_launches": (C.c_ulonglong, []),
     "mhh_diff_exec_viscosity_rows": (ci, [GP, ci, FP, DP, ci, ci, vp]),
+    "mhh_diff_exec_viscosity_rows2": (ci, [GP, ci, FP, DP, ci, ci, ci, ci, vp]),
     "mhh_rhs_exec_rows": (ci, [GP, ci, ci, FP, DP, ci, ci, vp]),
+    "mhh_rhs_exec_rows2": (ci, [GP, ci, ci, FP, DP, ci, ci, ci, ci, vp]),
     "mhh_stat_rhs44_march_launches": (C.c_ulonglong, []),
     "mhh_thermo_dry_buoyancy_tend": (ci, [GP, ci, vp, vp, vp, cd, vp]),
     "mhh_advec_cfl": (ci, [GP, ci, vp, vp, vp, cd, vp, C.POINTER(cd), vp]),

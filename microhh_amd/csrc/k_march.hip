@@ -196,12 +196,13 @@ rhs25_march_kernel(const MarchMetrics<typename lane_of<VT>::scalar> mm, const Gr
     if (!decode_march(mt, blockIdx.x, bx, by, kcn)) return;        // whole block leaves together: no barrier hazard
     const int jj = g.icells, kk = g.ijcells;
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty*64 + tx;
-    const int i0 = g.istart + bx*64*CW, j0 = mt.jbase + by*NJ;
+    int j0, jlim; march_tile_rows(mt, by, NJ, j0, jlim);
+    const int i0 = g.istart + bx*64*CW;
     const int kb = g.kstart + kcn*mt.kc;
     const int ke = (kb + mt.kc < g.kend) ? kb + mt.kc : g.kend;
     const int i = i0 + tx, j = j0 + ty;                             // the lane's (first) cell; CW = 2 needs whole 128-cell tiles (the launcher checks)
-    const bool active = (i + SEC < g.iend) && (j < mt.jlim);
-    const int ci = (i + SEC < g.iend) ? i : g.iend-1-SEC, cj = (j < mt.jlim) ? j : mt.jlim-1;   // clamped column for the window loads
+    const bool active = (i + SEC < g.iend) && (j < jlim);
+    const int ci = (i + SEC < g.iend) ? i : g.iend-1-SEC, cj = (j < jlim) ? j : jlim-1;   // clamped column for the window loads
     const int col = ci + cj*jj;
     const int ij = col;
     const int l = (ty+3)*TI + (tx+HX), le = (ty+1)*TE + (tx+EX);
@@ -746,7 +747,7 @@ template<class TF> bool known_divisor_ok(TF d)
 // mode 0: advec_2i5 + diff_smag2 (the fused pass); 1: advec_2i5 only (p may be null); 2: diff_smag2 only
 // VT = lane value type: double, float, or F2 = two fp32 cells per lane (packed arithmetic; needs an even imax)
 template<class VT>
-int march_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, int j0, int j1, hipStream_t st, int mode = 0)
+int march_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, int j0, int j1, hipStream_t st, int mode = 0, int j2 = -1, int j3 = -1)
 {
     using TF = typename lane_of<VT>::scalar;
     constexpr int CW = lane_of<VT>::cells;
@@ -774,12 +775,12 @@ int march_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* 
 #define MHH_MARCH_KC 128
 #endif
     // a strip of a few rows (mhh_rhs_exec_rows on the edge rows) takes short k-chunks: enough blocks to fill the GPU
-    int kc = (j0 >= 0 && (j1 - j0) * 4 <= g->jmax) ? 16 : MHH_MARCH_KC;
+    int kc = (j0 >= 0 && (j1 - j0 + (j2 >= 0 ? j3 - j2 : 0)) * 4 <= g->jmax) ? 16 : MHH_MARCH_KC;
     // the lanes address a chunk's planes with 32-bit byte offsets from the chunk's first plane: (kc + 8) planes below 4 GB
     const unsigned long long plane_bytes = (unsigned long long)g->ijcells * sizeof(TF);
     while (kc > 8 && (unsigned long long)(kc + 8) * plane_bytes >= (1ull << 32)) kc /= 2;
     MHH_REQUIRE((unsigned long long)(kc + 8) * plane_bytes < (1ull << 32), "a plane of this grid is too large for the marching kernel's 32-bit lane offsets");
-    const MarchTiling t = make_march_tiling(g, NJ, kc, j0, j1, 64*CW);
+    const MarchTiling t = make_march_tiling(g, NJ, kc, j0, j1, 64*CW, j2, j3);
     const unsigned nblocks = march_blocks(t);
 #ifdef MHH_MARCH_STAMP
     if (g_stamp_n < (size_t)nblocks*NJ*8) { if (g_stamp_buf) (void)hipFree(g_stamp_buf); g_stamp_n = (size_t)nblocks*NJ*8; MHH_HIP_TRY(hipMalloc(&g_stamp_buf, g_stamp_n*8)); }
@@ -825,16 +826,18 @@ static bool f32x2(const mhh_grid* g)
     const char* e = getenv("MHH_MARCH_F32X2");
     return g->imax % 128 == 0 && !(e && !strcmp(e, "0"));
 }
-static int march_dispatch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, int j0, int j1, void* stream, int mode)
+static int march_dispatch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, int j0, int j1, void* stream, int mode, int j2 = -1, int j3 = -1)
 {
-    if (g->dtype == MHH_F64) return march_launch<double>(g, f, p, j0, j1, as_stream(stream), mode);
-    if (f32x2(g)) return march_launch<F2>(g, f, p, j0, j1, as_stream(stream), mode);
-    return march_launch<float>(g, f, p, j0, j1, as_stream(stream), mode);
+    if (g->dtype == MHH_F64) return march_launch<double>(g, f, p, j0, j1, as_stream(stream), mode, j2, j3);
+    if (f32x2(g)) return march_launch<F2>(g, f, p, j0, j1, as_stream(stream), mode, j2, j3);
+    return march_launch<float>(g, f, p, j0, j1, as_stream(stream), mode, j2, j3);
 }
 // entry used by mhh_rhs_exec for the (advec_2i5, diff_smag2) pair: u, v, w and scalar 0 (inputs validated by the caller)
 int mhh_rhs25_march(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, void* stream) { return march_dispatch(g, f, p, -1, -1, stream, 0); }
 // the same over the rows [j0, j1) only (interior rows while the halos travel, edge rows after: mhh_rhs_exec_rows)
 int mhh_rhs25_march_rows(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, int j0, int j1, void* stream) { return march_dispatch(g, f, p, j0, j1, stream, 0); }
+// two row ranges in one launch (the two edge strips of a slab)
+int mhh_rhs25_march_rows2(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, int j0, int j1, int j2, int j3, void* stream) { return march_dispatch(g, f, p, j0, j1, stream, 0, j2, j3); }
 
 // Advec_2i5::exec / Diff_smag2::exec on their own, for u, v, w and scalar 0 (inputs validated by the caller): the marching
 // kernel with one operator's terms only -- what the two calls of an unfused time step run.

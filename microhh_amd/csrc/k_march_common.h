@@ -7,7 +7,14 @@
 
 namespace mhh
 {
-struct MarchTiling { int nbx, nby, nkc, sr, ns, kc, jbase, jlim; };   // rows [jbase, jlim) are worked, in tiles from jbase
+// rows [jbase, jlim) are worked, in tiles from jbase; optionally a SECOND range [jbase2, jlim2) in the same launch (the two edge
+// strips of a slab once its north-south halos have arrived: one launch instead of two): tile rows by >= nby1 belong to it
+struct MarchTiling { int nbx, nby, nkc, sr, ns, kc, jbase, jlim, nby1, jbase2, jlim2; };
+__device__ __forceinline__ void march_tile_rows(const MarchTiling& t, int by, int NJ, int& j0, int& jlim)
+{
+    if (by < t.nby1) { j0 = t.jbase + by*NJ; jlim = t.jlim; }
+    else             { j0 = t.jbase2 + (by - t.nby1)*NJ; jlim = t.jlim2; }
+}
 
 __device__ __forceinline__ bool decode_march(const MarchTiling& t, unsigned L, int& bx, int& by, int& kc)
 {
@@ -31,11 +38,13 @@ __device__ __forceinline__ bool decode_march(const MarchTiling& t, unsigned L, i
 // strips of sr tile rows; (strip, k-chunk) units are dealt round-robin to the XCDs; sr shrinks on thin slabs so that all
 // 8 XCDs get work
 // tw = cells of a row per tile (a wave's 64 lanes times the cells per lane)
-inline MarchTiling make_march_tiling(const mhh_grid* g, int NJ, int kc, int j0 = -1, int j1 = -1, int tw = 64)
+inline MarchTiling make_march_tiling(const mhh_grid* g, int NJ, int kc, int j0 = -1, int j1 = -1, int tw = 64, int j2 = -1, int j3 = -1)
 {
     MarchTiling t;
     t.jbase = (j0 < 0) ? g->jstart : j0; t.jlim = (j1 < 0) ? g->jend : j1;
-    t.nbx = (g->imax + tw-1)/tw; t.nby = (t.jlim - t.jbase + NJ-1)/NJ;
+    t.nbx = (g->imax + tw-1)/tw; t.nby1 = (t.jlim - t.jbase + NJ-1)/NJ; t.nby = t.nby1;
+    t.jbase2 = t.jlim2 = t.jlim;
+    if (j2 >= 0 && j3 > j2) { t.jbase2 = j2; t.jlim2 = j3; t.nby += (j3 - j2 + NJ-1)/NJ; }
     t.kc = kc; t.nkc = (g->kmax + t.kc - 1)/t.kc;
     t.sr = (MHH_STRIP_ROWS + NJ-1)/NJ;
     if (t.sr * 8 > t.nby * t.nkc) t.sr = (t.nby * t.nkc) / 8;

@@ -12,6 +12,8 @@ int mhh_rhs25_march(const mhh_grid* g, const mhh_fields* f, const mhh_diff_param
 int mhh_diff_smag2_march(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, void* stream);   // k_march.hip
 int mhh_visc_march(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, const void* th, void* stream);   // k_visc.hip
 int mhh_visc_march_rows(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, const void* th, int j0, int j1, void* stream);
+int mhh_visc_march_rows2(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, const void* th, int j0, int j1, int j2, int j3, void* stream);
+int mhh_rhs25_march_rows2(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, int j0, int j1, int j2, int j3, void* stream);   // k_march.hip
 int mhh_rhs25_march_rows(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, int j0, int j1, void* stream);   // k_march.hip
 int mhh_rhs44_march(const mhh_grid* g, const mhh_fields* f, void* stream);
 int mhh_diff4_march(const mhh_grid* g, const mhh_fields* f, void* stream);                                           // k_march4.hip
@@ -151,7 +153,7 @@ struct MirrorWallOp2
 
 // rows [j0, j1) (j0 < 0: the interior, plus the two adjacent ghost rows when p->evisc_ghost_rows), then the wall mirror
 // and the east-west wrap over all rows
-static int viscosity_rows(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, int j0, int j1, void* stream)
+static int viscosity_rows(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, int j0, int j1, void* stream, int j2 = -1, int j3 = -1)
 {
     MHH_REQUIRE(f && p && f->evisc && f->u && f->v && f->w && p->mlen0, "null field");
     MHH_REQUIRE(!p->surface_model || (f->dudz && f->dvdz && f->z0m), "surface model inputs");
@@ -171,12 +173,13 @@ static int viscosity_rows(const mhh_grid* g, const mhh_fields* f, const mhh_diff
     const bool whole = (j0 < 0);
     const int ja = whole ? g->jstart : j0, jb = whole ? g->jend : j1;
     // the k-marching LDS kernel (k_visc.hip), or one thread per cell where it declines
-    const int marched = whole ? mhh_visc_march(g, f, p, th, stream) : mhh_visc_march_rows(g, f, p, th, ja, jb, stream);
+    const int marched = whole ? mhh_visc_march(g, f, p, th, stream) : mhh_visc_march_rows2(g, f, p, th, ja, jb, j2, j3, stream);
 #define CALL(TF) [&]{ ViscosityOp<TF> op{make_grid<TF>(g), p->surface_model, p->neutral, mp<TF>(f->evisc), cp<TF>(f->u), cp<TF>(f->v), cp<TF>(f->w), \
                           cp<TF>(f->dudz), cp<TF>(f->dvdz), cp<TF>(f->dbdz), cp<TF>(f->z0m), cp<TF>(p->N2), cp<TF>(th), cp<TF>(p->thref), TF(p->grav), cp<TF>(p->mlen0), TF(p->tPr), cp<TF>(p->mlen2)}; \
                       if (marched < 0) return -marched; \
                       if (!marched) { if (whole) { if (int e = launch_interior(st, op.g, g->kstart, g->kend, op)) return e; } \
-                                      else if (int e = launch_cells(st, op, g->istart, g->iend, ja, jb, g->kstart, g->kend, g->icells, g->ijcells)) return e; } \
+                                      else { if (int e = launch_cells(st, op, g->istart, g->iend, ja, jb, g->kstart, g->kend, g->icells, g->ijcells)) return e; \
+                                             if (j2 >= 0) if (int e = launch_cells(st, op, g->istart, g->iend, j2, j3, g->kstart, g->kend, g->icells, g->ijcells)) return e; } } \
                       if (whole && p->evisc_ghost_rows) { \
                           if (int e = launch_cells(st, op, g->istart, g->iend, g->jstart-1, g->jstart, g->kstart, g->kend, g->icells, g->ijcells)) return e; \
                           if (int e = launch_cells(st, op, g->istart, g->iend, g->jend, g->jend+1, g->kstart, g->kend, g->icells, g->ijcells)) return e; } \
@@ -200,6 +203,15 @@ MHH_API int mhh_diff_exec_viscosity_rows(const mhh_grid* g, int scheme, const mh
     MHH_REQUIRE(j0 >= g->jstart-1 && j0 < j1 && j1 <= g->jend+1, "rows must lie in [jstart-1, jend+1)");
     MHH_REQUIRE((j0 >= g->jstart && j1 <= g->jend) || g->jgc >= 2, "ghost rows need jgc >= 2");
     return viscosity_rows(g, f, p, j0, j1, stream);
+}
+// two row ranges in ONE launch (+ one wall mirror and one east-west wrap): the two edge strips of a slab once its halos are in
+MHH_API int mhh_diff_exec_viscosity_rows2(const mhh_grid* g, int scheme, const mhh_fields* f, const mhh_diff_params* p, int j0, int j1, int j2, int j3, void* stream)
+{
+    if (int e = check_grid(g)) return e;
+    if (scheme != MHH_DIFF_SMAG2) return MHH_OK;
+    MHH_REQUIRE(j0 >= g->jstart-1 && j0 < j1 && j1 <= j2 && j2 < j3 && j3 <= g->jend+1, "two disjoint, ordered row ranges in [jstart-1, jend+1)");
+    MHH_REQUIRE((j0 >= g->jstart && j3 <= g->jend) || g->jgc >= 2, "ghost rows need jgc >= 2");
+    return viscosity_rows(g, f, p, j0, j1, stream, j2, j3);
 }
 
 // Diff::exec (src/diff_2.cxx:150-180, src/diff_4.cxx:250-300, src/diff_smag2.cxx:939-1043), unfused
@@ -541,4 +553,21 @@ MHH_API int mhh_rhs_exec_rows(const mhh_grid* g, int advec_scheme, int diff_sche
         if (f->nscalars) MHH_REQUIRE(f->s_fluxbot[0] && f->s_fluxtop[0], "scalar surface fluxes");
     }
     return mhh_rhs25_march_rows(g, f, p, j0, j1, stream);
+}
+// the same over two row ranges in one launch (the two edge strips of a slab)
+MHH_API int mhh_rhs_exec_rows2(const mhh_grid* g, int advec_scheme, int diff_scheme, const mhh_fields* f, const mhh_diff_params* p, int j0, int j1, int j2, int j3, void* stream)
+{
+    if (int e = check_grid(g)) return e;
+    MHH_REQUIRE(advec_scheme == MHH_ADVEC_2I5 && diff_scheme == MHH_DIFF_SMAG2, "row-wise pass: (advec_2i5, diff_smag2) only");
+    MHH_REQUIRE(f && p && f->u && f->v && f->w && f->ut && f->vt && f->wt && f->evisc && f->rhoref && f->rhorefh, "null field");
+    MHH_REQUIRE(f->nscalars >= 0 && f->nscalars <= 1 && (f->nscalars == 0 || (f->s[0] && f->st[0] && !f->s_fluxlimit[0])), "row-wise pass: at most one, unlimited scalar");
+    MHH_REQUIRE(!p->buoyancy || (p->buoyancy == 2 && p->th_for_N2 == 0 && f->nscalars == 1 && p->threfh), "row-wise pass: buoyancy only as the in-kernel 2nd-order form of scalar 0");
+    MHH_REQUIRE(g->igc >= 3 && g->jgc >= 3 && g->kgc >= 1 && g->ktot >= 6, "advec_2i5 needs gc(3,3,1), ktot>=6");
+    MHH_REQUIRE(j0 >= g->jstart && j0 < j1 && j1 <= j2 && j2 < j3 && j3 <= g->jend, "two disjoint, ordered row ranges in [jstart, jend)");
+    if (p->surface_model)
+    {
+        MHH_REQUIRE(f->u_fluxbot && f->u_fluxtop && f->v_fluxbot && f->v_fluxtop, "surface fluxes");
+        if (f->nscalars) MHH_REQUIRE(f->s_fluxbot[0] && f->s_fluxtop[0], "scalar surface fluxes");
+    }
+    return mhh_rhs25_march_rows2(g, f, p, j0, j1, j2, j3, stream);
 }

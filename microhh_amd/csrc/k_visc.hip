@@ -51,12 +51,13 @@ __global__ void __launch_bounds__(64*NJ, MHH_VISC_OCC) visc_march_kernel(const G
     if (!decode_march(mt, blockIdx.x, bx, by, kcn)) return;
     const int jj = g.icells, kk = g.ijcells;
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty*64 + tx;
-    const int i0 = g.istart + bx*64, j0 = mt.jbase + by*NJ;
+    int j0, jlim; march_tile_rows(mt, by, NJ, j0, jlim);
+    const int i0 = g.istart + bx*64;
     const int kb = g.kstart + kcn*mt.kc;
     const int ke = (kb + mt.kc < g.kend) ? kb + mt.kc : g.kend;
     const int i = i0 + tx, j = j0 + ty;
-    const bool active = (i < g.iend) && (j < mt.jlim);
-    const int ci = (i < g.iend) ? i : g.iend-1, cj = (j < mt.jlim) ? j : mt.jlim-1;
+    const bool active = (i < g.iend) && (j < jlim);
+    const int ci = (i < g.iend) ? i : g.iend-1, cj = (j < jlim) ? j : jlim-1;
     const int col = ci + cj*jj, ij = col;
     const int l = (ty+1)*TI + (tx+f.ex);
     auto slot = [](int p) { return (p + 12) % R; };
@@ -162,7 +163,7 @@ __global__ void __launch_bounds__(64*NJ, MHH_VISC_OCC) visc_march_kernel(const G
 }
 
 template<class TF>
-int visc_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, const void* th, int ex, int pb, int j0, int j1, hipStream_t st)
+int visc_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, const void* th, int ex, int pb, int j0, int j1, hipStream_t st, int j2 = -1, int j3 = -1)
 {
     constexpr int NJ = 4;
     ViscFields<TF> vf;
@@ -170,8 +171,8 @@ int visc_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p
     vf.dudz = cp<TF>(f->dudz); vf.dvdz = cp<TF>(f->dvdz); vf.dbdz = cp<TF>(f->dbdz); vf.z0m = cp<TF>(f->z0m);
     vf.N2 = cp<TF>(p->N2); vf.th = cp<TF>(th); vf.thref = cp<TF>(p->thref); vf.mlen0 = cp<TF>(p->mlen0); vf.mlen2 = cp<TF>(p->mlen2);
     vf.grav = TF(p->grav); vf.tPr = TF(p->tPr); vf.sm = p->surface_model; vf.neutral = p->neutral; vf.ex = ex;
-    const int kc = (j0 >= 0 && (j1 - j0) * 4 <= g->jmax) ? 16 : MHH_VISC_KC;      // few rows: short k-chunks fill the GPU
-    const MarchTiling t = make_march_tiling(g, NJ, kc, j0, j1);
+    const int kc = (j0 >= 0 && (j1 - j0 + (j2 >= 0 ? j3 - j2 : 0)) * 4 <= g->jmax) ? 16 : MHH_VISC_KC;      // few rows: short k-chunks fill the GPU
+    const MarchTiling t = make_march_tiling(g, NJ, kc, j0, j1, 64, j2, j3);
     const dim3 nb(march_blocks(t)), bs(64, NJ);
     const GridDev<TF> gd = make_grid<TF>(g);
     if (vf.N2)
@@ -196,11 +197,13 @@ MHH_API unsigned long long mhh_stat_visc_march_launches(void) { return g_visc_ma
 // Entry used by mhh_diff_exec_viscosity (inputs validated there). Returns 1 when the marching kernel ran, 0 when it is
 // switched off (MHH_VISC_IMPL=cell) or the grid has no ghost cells to read (the caller then takes the cell kernel),
 // < 0 on error (-code).
-int mhh_visc_march_rows(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, const void* th, int j0, int j1, void* stream);
+int mhh_visc_march_rows2(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, const void* th, int j0, int j1, int j2, int j3, void* stream);
+int mhh_visc_march_rows(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, const void* th, int j0, int j1, void* stream)
+{ return mhh_visc_march_rows2(g, f, p, th, j0, j1, -1, -1, stream); }
 int mhh_visc_march(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, const void* th, void* stream)
 { return mhh_visc_march_rows(g, f, p, th, -1, -1, stream); }
-// rows [j0, j1) only (-1, -1: the interior); ghost rows jstart-1 and jend are legal when jgc >= 2
-int mhh_visc_march_rows(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, const void* th, int j0, int j1, void* stream)
+// rows [j0, j1) only (-1, -1: the interior) and optionally [j2, j3) in the same launch; ghost rows jstart-1 and jend are legal when jgc >= 2
+int mhh_visc_march_rows2(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p, const void* th, int j0, int j1, int j2, int j3, void* stream)
 {
     { const char* e = getenv("MHH_VISC_IMPL"); if (e && !strcmp(e, "cell")) return 0; }     // A/B switch, read per call
     const int vec = (g->dtype == MHH_F64) ? 2 : 4;
@@ -214,6 +217,6 @@ int mhh_visc_march_rows(const mhh_grid* g, const mhh_fields* f, const mhh_diff_p
     const int pb = ex ? 16 : 4;
     if (!ex) ex = 1;
     ++g_visc_march_launches;
-    const int rc = (g->dtype == MHH_F64) ? visc_launch<double>(g, f, p, th, ex, pb, j0, j1, as_stream(stream)) : visc_launch<float>(g, f, p, th, ex, pb, j0, j1, as_stream(stream));
+    const int rc = (g->dtype == MHH_F64) ? visc_launch<double>(g, f, p, th, ex, pb, j0, j1, as_stream(stream), j2, j3) : visc_launch<float>(g, f, p, th, ex, pb, j0, j1, as_stream(stream), j2, j3);
     return rc == MHH_OK ? 1 : -rc;
 }

@@ -339,6 +339,23 @@ class Diff
             mhh_grid g = grid.abi(); mhh_fields f = abi_fields(fields, &boundary); mhh_diff_params p = params(&thermo);
             mhh_check(mhh_diff_exec_viscosity(&g, scheme, &f, &p, stream));
         }
+        // rows [j0, j1) (and, if j2 >= 0, [j2, j3) in the same launch) of exec_viscosity on a y-slab whose evisc ghost rows jstart-1
+        // and jend are evaluated locally from the velocity halos instead of being exchanged (mhh_host_rccl.h, Substep_slab)
+        void exec_viscosity_rows(Thermo<TF>& thermo, int j0, int j1, int j2 = -1, int j3 = -1, void* stream = nullptr)
+        {
+            if (scheme != MHH_DIFF_SMAG2) return;
+            mhh_grid g = grid.abi(); mhh_fields f = abi_fields(fields, &boundary); mhh_diff_params p = params(&thermo);
+            p.evisc_ghost_rows = 1;
+            if (j2 < 0) mhh_check(mhh_diff_exec_viscosity_rows(&g, scheme, &f, &p, j0, j1, stream));
+            else        mhh_check(mhh_diff_exec_viscosity_rows2(&g, scheme, &f, &p, j0, j1, j2, j3, stream));
+        }
+        // advec->exec + diff->exec on the rows [j0, j1) (and [j2, j3)): (advec_2i5, diff_smag2) only
+        void exec_with_advec_rows(Advec<TF>& advec, int j0, int j1, int j2 = -1, int j3 = -1, void* stream = nullptr)
+        {
+            mhh_grid g = grid.abi(); mhh_fields f = abi_fields(fields, &boundary); mhh_diff_params p = params(nullptr);
+            if (j2 < 0) mhh_check(mhh_rhs_exec_rows(&g, advec.get_scheme(), scheme, &f, &p, j0, j1, stream));
+            else        mhh_check(mhh_rhs_exec_rows2(&g, advec.get_scheme(), scheme, &f, &p, j0, j1, j2, j3, stream));
+        }
         void exec(Stats&, void* stream = nullptr)
         {
             if (scheme == 0) return;

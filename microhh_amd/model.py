@@ -377,10 +377,9 @@ class HotPath:
         self.rhs_rows_timed = jb - ja
         if self.on_gpu:
             torch.cuda.current_stream(self.device).wait_event(self._ev[1])
-        self._ok(lib.mhh_diff_exec_viscosity_rows(self.G, dif, F, P, g.jstart - 1, g.jstart + 1, self.stream))
-        self._ok(lib.mhh_diff_exec_viscosity_rows(self.G, dif, F, P, g.jend - 1, g.jend + 1, self.stream))
-        self._ok(lib.mhh_rhs_exec_rows(self.G, adv, dif, F, P, g.jstart, ja, self.stream))
-        self._ok(lib.mhh_rhs_exec_rows(self.G, adv, dif, F, P, jb, g.jend, self.stream))
+        # both edge strips in one launch each
+        self._ok(lib.mhh_diff_exec_viscosity_rows2(self.G, dif, F, P, g.jstart - 1, g.jstart + 1, g.jend - 1, g.jend + 1, self.stream))
+        self._ok(lib.mhh_rhs_exec_rows2(self.G, adv, dif, F, P, g.jstart, ja, jb, g.jend, self.stream))
 
     # -- the operator calls -----------------------------------------------------------------------------------
     def exec_viscosity(self):

@@ -29,7 +29,7 @@ int main(int argc, char** argv)
         Grid<TF> grid; auto& gd = grid.gd;
         gd.itot = hdr[0]; gd.jtot = hdr[1]; gd.ktot = hdr[2]; gd.igc = hdr[3]; gd.jgc = hdr[4]; gd.kgc = hdr[5];
         const int sm = hdr[6];
-        const bool fused = hdr[7] & 1, limited = hdr[7] & 2, buoy = hdr[7] & 4, slab = hdr[7] & 8;
+        const bool fused = hdr[7] & 1, limited = hdr[7] & 2, buoy = hdr[7] & 4, slab = hdr[7] & 8, overlap = hdr[7] & 16, sliced = hdr[7] & 32;
         gd.imax = gd.itot; gd.jmax = gd.jtot; gd.kmax = gd.ktot;
         gd.icells = gd.itot + 2*gd.igc; gd.jcells = gd.jtot + 2*gd.jgc; gd.kcells = gd.ktot + 2*gd.kgc; gd.ijcells = gd.icells*gd.jcells; gd.ncells = gd.ijcells*gd.kcells;
         gd.istart = gd.igc; gd.jstart = gd.jgc; gd.kstart = gd.kgc; gd.iend = gd.istart + gd.itot; gd.jend = gd.jstart + gd.jtot; gd.kend = gd.kstart + gd.ktot;
@@ -102,12 +102,25 @@ int main(int argc, char** argv)
             Pres_slab<TF> pres_slab(master, grid, fields);
             pres_slab.set_reduce_workspace(work);
             pres_slab.prepare_device();
+            if (sliced) { pres_slab.set_chunks(4); if (pres_slab.chunks() != 4) { std::fprintf(stderr, "set_chunks\n"); return 7; } }   // k-sliced transposes on a second stream
+            if (overlap)
+            {
+                // the prognostic halos travel on a stream of their own while the rows that need none are worked; edge strips in one launch each
+                Substep_slab<TF> sub(master, grid, fields, halo);
+                if (!sub.can_overlap(*advec, *diff)) { std::fprintf(stderr, "can_overlap\n"); return 7; }
+                sub.halo_visc_rhs(*advec, *diff, thermo);
+                cfl = master.max(advec->get_cfl(dt));
+                dnum = master.max(diff->get_dn(dt));
+            }
+            else
+            {
             halo.exec_g({fields.mp["u"]->fld_g, fields.mp["v"]->fld_g, fields.mp["w"]->fld_g, fields.sp["th"]->fld_g});   // one message pair for all four
             diff->exec_viscosity(thermo);
             cfl = master.max(advec->get_cfl(dt));
             dnum = master.max(diff->get_dn(dt));
             if (fused) diff->exec_with_advec(*advec, stats, nullptr, buoy ? &thermo : nullptr);
             else     { if (buoy) thermo.exec(grid, fields); advec->exec(stats); diff->exec(stats); }
+            }
             pres_slab.exec(dt, stats);
             div = pres_slab.check_divergence();
             HIPCHK(hipDeviceSynchronize());

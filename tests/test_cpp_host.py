@@ -23,13 +23,17 @@ def test_host_header_is_self_contained():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5, 8, 9], ids=["two-calls", "fused", "two-calls-limited", "fused-limited", "two-calls-buoyancy", "fused-buoyancy",
-                                                              "slab-rccl-two-calls", "slab-rccl-fused"])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5, 8, 9, 25, 41, 57], ids=["two-calls", "fused", "two-calls-limited", "fused-limited", "two-calls-buoyancy", "fused-buoyancy",
+                                                                          "slab-rccl-two-calls", "slab-rccl-fused", "slab-rccl-overlapped-halos", "slab-rccl-sliced-transposes",
+                                                                          "slab-rccl-overlapped-and-sliced"])
 def test_cpp_host_substep_matches_oracle(mode):
     """mode bit 0: advec->exec + diff->exec as the fused pass; bit 1: "th" in advec.fluxlimit_list (kgc = 2);
     bit 2: Thermo_dry buoyancy (thermo->exec before advec, or folded into the fused pass); bit 3: the slab code path of
     microhh_amd/host/mhh_host_rccl.h (north-south halos by ncclSend / ncclRecv, the pressure solve around two grouped all-to-alls,
-    maxima by ncclAllReduce) on a one-rank RCCL communicator -- same oracle, same tolerances."""
+    maxima by ncclAllReduce) on a one-rank RCCL communicator -- same oracle, same tolerances; bit 4: the overlapped sub-step of the
+    C++ driver (Substep_slab: prognostic halos on an exchange stream while the interior rows are worked, both edge strips in one
+    launch per operator); bit 5: the pressure solve in four k-slices whose all-to-alls run on a second stream (Pres_slab::set_chunks).
+    The grid has 24 rows = three strips of eight, so the slab solves take the x stages with the transforms in LDS."""
     subprocess.run(["make", "-s", "-C", CPP], check=True)
     g = cm.grid_2nd(32, 24, 16, gc=(3, 3, 2 if mode & 2 else 1), stretched=False)
     c = cm.Case(g, rho="one")
