@@ -116,19 +116,24 @@ def cpu_baseline(case, sample=(256, 256, 256), reps=3, with_pres=True):
         parts.append((tt["ref"], tt["port"]))
     k = int(np.argsort(ts)[len(ts)//2])
     t = float(ts[k])
+    ref_s, port_s = parts[k]
     return {"value": it*jt*kt / t, "unit": "grid-cell updates/s", "cores": 1, "kind": "reference" if use_ref else "port",
-            "seconds_per_step": t, "reference_kernels_s": parts[k][0], "port_s": parts[k][1],
+            "seconds_per_step": t, "reference_kernels_s": ref_s, "port_s": port_s,
+            # the reference's own kernels alone (Advec::exec + Diff::exec + calc_strain2): cells per second of THAT part of the step
+            "reference_kernels_rate": (it*jt*kt / ref_s) if (use_ref and ref_s > 0) else None,
+            "reference_share_of_step": (ref_s / t) if use_ref else 0.0,
             "sample": ("%s %dx%dx%d (whole grid of this size, same case set-up), %d reps median, 1 thread of %d host cores; "
                        "Advec::exec + Diff::exec + calc_strain2 = the reference's own translation units (oracle/_ref/libmhhref_perf.so, "
-                       "-O3 -march=native -DNDEBUG); cyclic fills, N2 + calc_evisc and Pres::exec = the oracle port, same flags "
-                       "(pres FFT: the port's radix-2 code, not FFTW)" if use_ref else
+                       "-O3 -march=native -DNDEBUG): %.0f %% of the step's time; cyclic fills, N2 + calc_evisc and Pres::exec = the oracle port, same flags "
+                       "(pres FFT: the port's radix-2 code, not FFTW): the other %.0f %%" if use_ref else
                        "%s %dx%dx%d, %d reps median, 1 thread of %d host cores; the oracle port only (reference library not present)")
-                      % (case, it, jt, kt, reps, os.cpu_count() or 0)}
+                      % ((case, it, jt, kt, reps, os.cpu_count() or 0, 100.*ref_s/t, 100.*port_s/t) if use_ref else (case, it, jt, kt, reps, os.cpu_count() or 0))}
 
 
 def recorded_traffic(workload, igc=None):
-    """HBM bytes per launch of the dominant kernel from the newest profiles/*_traffic.json that scripts/gpu_traffic.sh wrote for
-    this workload -- only if it was measured on the sources this run was built from (microhh_amd/stamp.py)."""
+    """HBM bytes and vector instructions per launch of the dominant kernel from the newest profiles/*_traffic.json that
+    scripts/gpu_traffic.sh wrote for this workload -- only if it was measured on the sources this run was built from
+    (microhh_amd/stamp.py). Returns (bytes, VALU instructions, source) or (None, None, None)."""
     import glob
     from microhh_amd.stamp import source_stamp
     best = None
@@ -140,8 +145,39 @@ def recorded_traffic(workload, igc=None):
         if d.get("workload") == workload and d.get("stamp") == source_stamp() and d.get("build", "default") == "default" and d.get("igc") == igc:
             best = (f, d)
     if best is None:
-        return None, None
-    return float(best[1]["total_bytes"]), os.path.relpath(best[0], ROOT) + " (recorded by rocprofv3 PMC passes on these sources, not measured in this run)"
+        return None, None, None
+    return (float(best[1]["total_bytes"]), best[1].get("valu_insts"),
+            os.path.relpath(best[0], ROOT) + " (recorded by rocprofv3 PMC passes on these sources, not measured in this run)")
+
+
+def sample_clock_and_power(fn, sync, seconds=1.6):
+    """Engine clock and socket power while `fn` (one kernel launch) loops for `seconds`: two rocm-smi samples from this process while
+    the GPU works. The fused RHS kernel runs at the board's power cap with the engine clock throttled below its 2.4 GHz maximum --
+    the limit its roofs have to be read against (profiles/r3_march_kernel.md). None where rocm-smi is not available."""
+    import re
+    import shutil
+    import subprocess
+    if not shutil.which("rocm-smi"):
+        return None
+    t0 = time.time(); got = []
+    while time.time() - t0 < seconds:
+        for _ in range(40):
+            fn()
+        if time.time() - t0 > 0.5 and len(got) < 2:          # the queue is now ~40 launches deep: the sample falls inside the work
+            try:
+                out = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showmaxpower"], capture_output=True, text=True, timeout=20).stdout
+            except (OSError, subprocess.SubprocessError):
+                return None
+            sclk = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", out)
+            pw = re.search(r"Current Socket Graphics Package Power \(W\): ([0-9.]+)", out)
+            cap = re.search(r"Max Graphics Package Power \(W\): ([0-9.]+)", out)
+            if sclk and pw:
+                got.append((int(sclk.group(1)), float(pw.group(1)), float(cap.group(1)) if cap else None))
+        sync()
+    if not got:
+        return None
+    return {"sclk_mhz": max(g[0] for g in got), "socket_w": max(g[1] for g in got), "cap_w": got[0][2], "samples": len(got),
+            "how": "rocm-smi sampled from this process while the fused RHS launch loops (outside the timed region)"}
 
 
 def main():
@@ -163,6 +199,7 @@ def main():
                          "tolerance stated in tests/test_fma_build.py) instead of the bit-exact default")
     ap.add_argument("--graph", action="store_true", help="N=1 on a GPU: the timed steps replay one hipGraph of a step (HotPath.capture_step); "
                     "the per-kernel event times then come from untimed call-by-call steps before them")
+    ap.add_argument("--no-power-sample", action="store_true", help="skip the rocm-smi clock / power sample (1.6 s of looping the fused RHS launch after the timed region)")
     ap.add_argument("--no-fma-line", action="store_true", help="skip the extra timing of the named FMA build (fma_build in the JSON line)")
     ap.add_argument("--igc", type=int, default=None, help="ghost cells in x (>= the case's own): the layout the reference's grid takes when an operator "
                     "calls Grid::set_minimum_ghost_cells (src/grid.cxx:435-439); 16 = rows of whole 128-byte lines at itot = 512 fp64. A second, NAMED line: "
@@ -307,10 +344,28 @@ def main():
         out["pressure"] = {"ms": float(np.mean([e[1].elapsed_time(e[3]) for e in events])),
                            "form": "transforms in LDS, 3 kernels (csrc/pres_lds.h)" if hp.lib.mhh_pres_exec_form(hp.plan) == 1 else "staged, rocFFT (csrc/k_pres.hip)"}
     out["build"] = args.build if not os.environ.get("MHH_LIB") or args.build == "fma" else os.path.basename(os.environ["MHH_LIB"])
+    valu_insts = None
     if world == 1 and not args.unfused and out["build"] == "default":
-        out["roofline"]["traffic"], src = recorded_traffic(args.workload, args.igc)      # FETCH_SIZE x 2 + WRITE_SIZE per launch, or null
+        out["roofline"]["traffic"], valu_insts, src = recorded_traffic(args.workload, args.igc)      # FETCH_SIZE x 2 + WRITE_SIZE per launch, or null
         if src:
             out["roofline"]["traffic_source"] = src
+    # The second roof of the dominant kernel: vector-instruction issue. A wave64 fp64 instruction occupies its SIMD for 4 cycles;
+    # 1024 SIMDs. `insts` = SQ_INSTS_VALU per launch from the same stamped PMC record as `traffic`; the floor is given at the chip's
+    # maximum engine clock and at the clock it actually holds under this kernel (sampled live below: the board runs it at its power cap).
+    power = None
+    if world == 1 and on_gpu and not args.unfused and not args.no_power_sample:
+        power = sample_clock_and_power(rhs, lambda: torch.cuda.synchronize())
+        if power:
+            out["power"] = power
+    if valu_insts:
+        f_max = 2.4e9
+        f_now = (power["sclk_mhz"] * 1e6) if power else None
+        floor = lambda f: valu_insts * 4.0 / (1024 * f) * 1e3           # ms  # noqa: E731
+        out["roofline"]["valu"] = {"bound": "vector-instruction issue (wave64 fp64: 4 cycles per instruction and SIMD, 1024 SIMDs)",
+                                   "insts_per_launch": valu_insts, "insts_per_cell": valu_insts * 64.0 / local_cells_rhs,
+                                   "floor_ms_at_2400_mhz": floor(f_max), "frac_at_2400_mhz": floor(f_max) / rhs_ms,
+                                   "floor_ms_at_sampled_clock": floor(f_now) if f_now else None,
+                                   "frac_at_sampled_clock": (floor(f_now) / rhs_ms) if f_now else None}
     if world == 1 and on_gpu and args.build == "default" and not args.unfused and not rhs_only and not args.no_fma_line and not os.environ.get("MHH_LIB") \
             and os.path.exists(os.path.join(ROOT, "microhh_amd", "libmhh_hip_fma.so")):
         # the same fused RHS launch from the named FMA build, timed the same way (its own fields; nothing of it enters `value`)

@@ -359,6 +359,10 @@ int mhh_boundary_ghost_cells_w(const mhh_grid* g, void* w, int type, void* strea
 
 /* ---- Timeloop RK3/RK4 substep (src/timeloop.cxx:250-334, src/timeloop.cu:35-122) -------- */
 int mhh_rk_substep(const mhh_grid* g, int rkorder, int substep, double dt, void* a, void* at, void* stream);
+/* pres->exec(sub_dt) followed by timeloop.exec() for u, v, w (src/model.cxx:411,484): the sub-step rides in the pres_2 kernel that
+ * stores the corrected tendencies (two array passes per field less than a separate kernel); the bits of mhh_pres_exec followed by
+ * mhh_rk_substep(u), (v), (w), which is also what it falls back to (pres_4, the last sub-step of a step). f->u, v, w are WRITTEN. */
+int mhh_pres_exec_rk(mhh_pres_plan* plan, const mhh_grid* g, const mhh_fields* f, double sub_dt, int rkorder, int substep, double dt, void* stream);
 
 #ifdef __cplusplus
 }

@@ -89,6 +89,7 @@ SIGNATURES = {
     "mhh_pres_output": (ci, [PLAN, GP, FP, vp]),
     "mhh_pres_check_divergence": (ci, [GP, ci, FP, vp, C.POINTER(cd), vp]),
     "mhh_rk_substep": (ci, [GP, ci, ci, cd, vp, vp, vp]),
+    "mhh_pres_exec_rk": (ci, [PLAN, GP, FP, C.c_double, ci, ci, C.c_double, vp]),
     "mhh_boundary_ghost_cells": (ci, [GP, ci, vp, ci, ci, vp, vp, vp, vp, vp]),
     "mhh_boundary_ghost_cells_w": (ci, [GP, vp, ci, vp]),
     "mhh_pres_input_packed": (ci, [GP, ci, FP, cd, vp, vp]),

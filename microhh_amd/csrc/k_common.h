@@ -157,4 +157,21 @@ template<bool POW2, class TF>
 __device__ __forceinline__ TF fft_norm(TF v, int itot, int jtot, TF ri, TF rj) { return POW2 ? (v * rj) * ri : v / jtot / itot; }
 static inline bool is_pow2(int n) { return n > 0 && (n & (n-1)) == 0; }
 
+
+// Low-storage Runge-Kutta coefficients of the time loop (src/timeloop.cxx:250-334): a += cB[substep]*dt*at, then at *= cA[next]
+// (or at = 0 over all cells when the next sub-step is the first of a new step)
+inline bool rk_coefficients(int rkorder, int substep, double& cA, double& cB, bool& reset)
+{
+    static const double A3[] = {0., -5./9., -153./128.};
+    static const double B3[] = {1./3., 15./16., 8./15.};
+    static const double A4[] = {0., -567301805773./1357537059087., -2404267990393./2016746695238., -3550918686646./2091501179385., -1275806237668./842570457699.};
+    static const double B4[] = {1432997174477./9575080441755., 5161836677717./13612068292357., 1720146321549./2090206949498., 3134564353537./4481467310338., 2277821191437./14882151754819.};
+    if (rkorder != 3 && rkorder != 4) return false;
+    const int ns = (rkorder == 3) ? 3 : 5;
+    if (substep < 0 || substep >= ns) return false;
+    const int nxt = (substep+1) % ns;
+    cA = (rkorder == 3) ? A3[nxt] : A4[nxt]; cB = (rkorder == 3) ? B3[substep] : B4[substep];
+    reset = (nxt == 0);
+    return true;
+}
 } // namespace mhh

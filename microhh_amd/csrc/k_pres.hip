@@ -50,6 +50,8 @@ struct mhh_pres_plan
     // the three-kernel form with the transforms in LDS (pres_lds.h): twiddle tables, w3 in its [k][kx][ky] layout
     void* tx = nullptr; void* ty = nullptr; void* w3l = nullptr;
     bool lds_ok = false;
+    // mhh_pres_exec_rk: the Runge-Kutta sub-step of u, v, w rides in the kernel that stores the corrected tendencies
+    bool rk_on = false; double rk_cA = 0, rk_cB = 0, rk_dt = 0; void* rk_u = nullptr; void* rk_v = nullptr; void* rk_w = nullptr;
 };
 
 
@@ -632,8 +634,10 @@ static int pres_column_solve(mhh_pres_plan* P, const mhh_grid* g, hipStream_t st
 template<bool POW2, class TF>
 __global__ void __launch_bounds__(256) unpack_out2_kernel(TF* __restrict__ p, const TF* __restrict__ packed,
                                                           TF* __restrict__ ut, TF* __restrict__ vt, TF* __restrict__ wt, const TF* __restrict__ dzhi,
-                                                          TF dxi, TF dyi, int itot, int jtot, int kmax, int igc, int jgc, int kgc, int icells, int jcells)
+                                                          TF dxi, TF dyi, int itot, int jtot, int kmax, int igc, int jgc, int kgc, int icells, int jcells,
+                                                          TF* __restrict__ u, TF* __restrict__ v, TF* __restrict__ w, TF cA, TF cB, TF rdt)
 {
+    // u != nullptr: the Runge-Kutta sub-step of u, v, w on the corrected tendencies (see pres_lds.h, PresLdsOut)
     const int ijc = chunk_of_block(blockIdx.x, gridDim.x)*256 + threadIdx.x;
     const int kz = blockIdx.z;                 // 0 .. kmax-1, kmax = the bottom ghost row
     if (ijc >= icells*jcells) return;
@@ -653,9 +657,19 @@ __global__ void __launch_bounds__(256) unpack_out2_kernel(TF* __restrict__ p, co
         const TF pw = fft_norm<POW2>(packed[(size_t)iw + (size_t)js *itot + (size_t)ks*ij], itot, jtot, ri, rj);
         const TF ps = fft_norm<POW2>(packed[(size_t)is + (size_t)jsm*itot + (size_t)ks*ij], itot, jtot, ri, rj);
         const TF pb = (ks == 0) ? pc : fft_norm<POW2>(packed[(size_t)is + (size_t)js*itot + (size_t)(ks-1)*ij], itot, jtot, ri, rj);   // p[kstart-1] = p[kstart]
-        ut[c] -= (pc - pw) * dxi;
-        vt[c] -= (pc - ps) * dyi;
-        wt[c] -= (pc - pb) * dzhi[kd];
+        if (u == nullptr)
+        {
+            ut[c] -= (pc - pw) * dxi;
+            vt[c] -= (pc - ps) * dyi;
+            wt[c] -= (pc - pb) * dzhi[kd];
+        }
+        else
+        {
+            const TF nut = ut[c] - (pc - pw) * dxi, nvt = vt[c] - (pc - ps) * dyi, nwt = wt[c] - (pc - pb) * dzhi[kd];
+            u[c] = u[c] + cB*rdt*nut; ut[c] = cA*nut;
+            v[c] = v[c] + cB*rdt*nvt; vt[c] = cA*nvt;
+            w[c] = w[c] + cB*rdt*nwt; wt[c] = cA*nwt;
+        }
     }
 }
 
@@ -1032,10 +1046,13 @@ MHH_API int mhh_pres_lds_stage(mhh_pres_plan* P, const mhh_grid* g, const mhh_fi
     else
     {
         MHH_REQUIRE(f && f->p && f->ut && f->vt && f->wt, "null field");
-#define M(TF, N) else if (nx == N) hipLaunchKernelGGL((lds_fft::pres_ifftx_out_kernel<TF, LDS_RG, (2 << N), N>), xgrid, dim3(P->itot), lds_bytes_x(P, 9), st, a);
+#define M(TF, N) else if (nx == N) { if (P->rk_on) hipLaunchKernelGGL((lds_fft::pres_ifftx_out_kernel<TF, LDS_RG, (2 << N), N, false, true>), xgrid, dim3(P->itot), lds_bytes_x(P, 9), st, a); \
+                                    else          hipLaunchKernelGGL((lds_fft::pres_ifftx_out_kernel<TF, LDS_RG, (2 << N), N>), xgrid, dim3(P->itot), lds_bytes_x(P, 9), st, a); }
 #define CALL(TF) [&]{ lds_fft::PresLdsOut<TF> a{make_grid<TF>(g), static_cast<const C2<TF>*>(P->spec), static_cast<const C2<TF>*>(P->tx), \
-                          mp<TF>(f->p), mp<TF>(f->ut), mp<TF>(f->vt), mp<TF>(f->wt), nx, kc, 0, P->ktot, P->jtot, {}}; \
-                      if (P->itot <= LDS_XS) hipLaunchKernelGGL((lds_fft::pres_ifftx_out_kernel<TF, LDS_RG, LDS_XS, 0>), xgrid, dim3(P->itot), lds_bytes_x(P, 9), st, a); \
+                          mp<TF>(f->p), mp<TF>(f->ut), mp<TF>(f->vt), mp<TF>(f->wt), nx, kc, 0, P->ktot, P->jtot, {}, \
+                          mp<TF>(P->rk_u), mp<TF>(P->rk_v), mp<TF>(P->rk_w), TF(P->rk_cA), TF(P->rk_cB), TF(P->rk_dt)}; \
+                      if (P->itot <= LDS_XS) { if (P->rk_on) hipLaunchKernelGGL((lds_fft::pres_ifftx_out_kernel<TF, LDS_RG, LDS_XS, 0, false, true>), xgrid, dim3(P->itot), lds_bytes_x(P, 9), st, a); \
+                                               else          hipLaunchKernelGGL((lds_fft::pres_ifftx_out_kernel<TF, LDS_RG, LDS_XS, 0>), xgrid, dim3(P->itot), lds_bytes_x(P, 9), st, a); } \
                       MHH_FOR_NX_T(M, TF) return MHH_OK; }()
         if (int e = MHH_DISPATCH(g, CALL)) return e;
 #undef CALL
@@ -1121,7 +1138,7 @@ int lds_slab_stage_out(const mhh_grid* g, const mhh_fields* f, const void* xbuf,
     const size_t lds = lds_slab_bytes_x(g->itot, g->dtype == MHH_F64 ? 8 : 4, 9);
 #define M(TF, N) else if (nx == N) hipLaunchKernelGGL((lds_fft::pres_ifftx_out_kernel<TF, LDS_RG, (2 << N), N, true>), xgrid, dim3(g->itot), lds, st, a);
 #define CALL(TF) [&]{ lds_fft::PresLdsOut<TF> a{make_grid<TF>(g), static_cast<const C2<TF>*>(xbuf), static_cast<const C2<TF>*>(tx), \
-                          mp<TF>(f->p), mp<TF>(f->ut), mp<TF>(f->vt), mp<TF>(f->wt), nx, kc, kbeg, kend, g->jmax, {nxb, npy, ks}}; \
+                          mp<TF>(f->p), mp<TF>(f->ut), mp<TF>(f->vt), mp<TF>(f->wt), nx, kc, kbeg, kend, g->jmax, {nxb, npy, ks}, nullptr, nullptr, nullptr, TF(0), TF(0), TF(0)}; \
                       if (g->itot <= LDS_XS) hipLaunchKernelGGL((lds_fft::pres_ifftx_out_kernel<TF, LDS_RG, LDS_XS, 0, true>), xgrid, dim3(g->itot), lds, st, a); \
                       MHH_FOR_NX_T(M, TF) return MHH_OK; }()
     if (int e = MHH_DISPATCH(g, CALL)) return e;
@@ -1177,11 +1194,12 @@ MHH_API int mhh_pres_exec(mhh_pres_plan* P, const mhh_grid* g, const mhh_fields*
             if (int e = pres_spectral(P, g, P->packed, st)) return e;
             dim3 ug((g->icells*g->jcells + 255)/256, 1, g->kmax + 1);
             const bool pow2 = is_pow2(g->itot) && is_pow2(g->jtot);
+#define RKARGS(TF) (P->rk_on ? mp<TF>(P->rk_u) : nullptr), mp<TF>(P->rk_v), mp<TF>(P->rk_w), TF(P->rk_cA), TF(P->rk_cB), TF(P->rk_dt)
 #define CALL(TF) [&]{ const GridDev<TF> gd = make_grid<TF>(g); \
                 if (pow2) hipLaunchKernelGGL((unpack_out2_kernel<true, TF>), ug, dim3(256), 0, st, mp<TF>(f->p), cp<TF>(P->packed), mp<TF>(f->ut), mp<TF>(f->vt), mp<TF>(f->wt), gd.dzhi, \
-                                   gd.dxi_t, gd.dyi_t, g->itot, g->jtot, g->kmax, g->igc, g->jgc, g->kgc, g->icells, g->jcells); \
+                                   gd.dxi_t, gd.dyi_t, g->itot, g->jtot, g->kmax, g->igc, g->jgc, g->kgc, g->icells, g->jcells, RKARGS(TF)); \
                 else hipLaunchKernelGGL((unpack_out2_kernel<false, TF>), ug, dim3(256), 0, st, mp<TF>(f->p), cp<TF>(P->packed), mp<TF>(f->ut), mp<TF>(f->vt), mp<TF>(f->wt), gd.dzhi, \
-                                   gd.dxi_t, gd.dyi_t, g->itot, g->jtot, g->kmax, g->igc, g->jgc, g->kgc, g->icells, g->jcells); return MHH_OK; }()
+                                   gd.dxi_t, gd.dyi_t, g->itot, g->jtot, g->kmax, g->igc, g->jgc, g->kgc, g->icells, g->jcells, RKARGS(TF)); return MHH_OK; }()
             if (int e = MHH_DISPATCH(g, CALL)) return e;
 #undef CALL
             MHH_LAUNCH_CHECK();
@@ -1218,4 +1236,30 @@ MHH_API int mhh_pres_exec(mhh_pres_plan* P, const mhh_grid* g, const mhh_fields*
     if (int e = pres_input_halos(g, P->order, f, stream)) return e;
     if (int e = (g->dtype == MHH_F64) ? pres_exec_fused<double>(P, g, f, dt, as_stream(stream)) : pres_exec_fused<float>(P, g, f, dt, as_stream(stream))) return e;
     return mhh_pres_output(P, g, f, stream);
+}
+
+// Pres::exec followed by the Runge-Kutta sub-step of u, v, w (timeloop.exec() in Model::exec, src/model.cxx:411,484;
+// src/timeloop.cxx:250-334): where the corrected tendencies are stored by a pres_2 kernel of this library (the LDS form's last stage,
+// the staged form's unpack + output kernel) the sub-step is applied there, in registers; otherwise -- pres_4, the two-kernel and
+// callback forms, the last sub-step of a step (the tendency reset covers the ghost cells) -- Pres::exec is followed by three
+// mhh_rk_substep calls. Either way the bits of mhh_pres_exec + mhh_rk_substep x 3. Scalars keep their own mhh_rk_substep call.
+MHH_API int mhh_pres_exec_rk(mhh_pres_plan* P, const mhh_grid* g, const mhh_fields* f, double dt, int rkorder, int substep, double rkdt, void* stream)
+{
+    MHH_REQUIRE(P != nullptr && f != nullptr && f->u && f->v && f->w && f->ut && f->vt && f->wt, "plan, fields");
+    double cA = 0, cB = 0; bool reset = false;
+    MHH_REQUIRE(rk_coefficients(rkorder, substep, cA, cB, reset), "rkorder 3 or 4, substep in range");
+    const char* uo = getenv("MHH_PRES_UNPACK_OUT"); const char* fe = getenv("MHH_PRES_FUSED"); const char* rke = getenv("MHH_PRES_RK_FUSED");
+    const bool one_kernel = mhh_pres_exec_form(P) == 1 || (P->order == 2 && !(uo && !strcmp(uo, "0")) && !(P->cb_ready && fe && !strcmp(fe, "1")));
+    const bool fuse = !reset && P->order == 2 && one_kernel && !(rke && !strcmp(rke, "0"));
+    if (fuse)
+    {
+        P->rk_on = true; P->rk_cA = cA; P->rk_cB = cB; P->rk_dt = rkdt; P->rk_u = f->u; P->rk_v = f->v; P->rk_w = f->w;
+        const int e = mhh_pres_exec(P, g, f, dt, stream);
+        P->rk_on = false;
+        return e;
+    }
+    if (int e = mhh_pres_exec(P, g, f, dt, stream)) return e;
+    if (int e = mhh_rk_substep(g, rkorder, substep, rkdt, f->u, f->ut, stream)) return e;
+    if (int e = mhh_rk_substep(g, rkorder, substep, rkdt, f->v, f->vt, stream)) return e;
+    return mhh_rk_substep(g, rkorder, substep, rkdt, f->w, f->wt, stream);
 }

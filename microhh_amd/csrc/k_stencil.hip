@@ -668,21 +668,14 @@ __global__ void __launch_bounds__(256) rk_kernel(TF* __restrict__ a, TF* __restr
 MHH_API int mhh_rk_substep(const mhh_grid* g, int rkorder, int substep, double dt, void* a, void* at, void* stream)
 {
     if (int e = check_grid(g)) return e;
-    MHH_REQUIRE(rkorder == 3 || rkorder == 4, "rkorder 3 or 4");
-    const int ns = (rkorder == 3) ? 3 : 5;
-    MHH_REQUIRE(substep >= 0 && substep < ns && a && at, "substep");
-    static const double A3[] = {0., -5./9., -153./128.};
-    static const double B3[] = {1./3., 15./16., 8./15.};
-    static const double A4[] = {0., -567301805773./1357537059087., -2404267990393./2016746695238., -3550918686646./2091501179385., -1275806237668./842570457699.};
-    static const double B4[] = {1432997174477./9575080441755., 5161836677717./13612068292357., 1720146321549./2090206949498., 3134564353537./4481467310338., 2277821191437./14882151754819.};
-    const int nxt = (substep+1) % ns;
-    const double cA = (rkorder == 3) ? A3[nxt] : A4[nxt], cB = (rkorder == 3) ? B3[substep] : B4[substep];
+    double cA = 0, cB = 0; bool reset = false;
+    MHH_REQUIRE(rk_coefficients(rkorder, substep, cA, cB, reset) && a && at, "rkorder 3 or 4, substep in range, fields");
     dim3 grid((g->icells+255)/256, g->jcells, g->kcells);
     if (g->dtype == MHH_F64)
-        hipLaunchKernelGGL(rk_kernel<double>, grid, dim3(256), 0, as_stream(stream), mp<double>(a), mp<double>(at), cA, cB, dt, nxt == 0,
+        hipLaunchKernelGGL(rk_kernel<double>, grid, dim3(256), 0, as_stream(stream), mp<double>(a), mp<double>(at), cA, cB, dt, reset ? 1 : 0,
                            g->icells, g->jcells, g->kcells, g->istart, g->iend, g->jstart, g->jend, g->kstart, g->kend);
     else
-        hipLaunchKernelGGL(rk_kernel<float>, grid, dim3(256), 0, as_stream(stream), mp<float>(a), mp<float>(at), (float)cA, (float)cB, (float)dt, nxt == 0,
+        hipLaunchKernelGGL(rk_kernel<float>, grid, dim3(256), 0, as_stream(stream), mp<float>(a), mp<float>(at), (float)cA, (float)cB, (float)dt, reset ? 1 : 0,
                            g->icells, g->jcells, g->kcells, g->istart, g->iend, g->jstart, g->jend, g->kstart, g->kend);
     MHH_LAUNCH_CHECK();
     return MHH_OK;

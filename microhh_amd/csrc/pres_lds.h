@@ -574,10 +574,14 @@ struct PresLdsOut
     int kbeg, kend;                   // the levels of this launch
     int nrows;                        // rows worked: jtot, or the rank's jmax
     LdsSlab sl;                       // SLAB only
+    TF* u; TF* v; TF* w; TF cA, cB, rdt;   // RK only: the sub-step of the time integration for u, v, w (src/timeloop.cxx:250-334)
 };
+// RK: the corrected tendency of u, v, w is final when it is stored here, so the Runge-Kutta sub-step that follows Pres::exec in
+// Model::exec (src/model.cxx:411,484; a += cB*dt*at, at *= cA) is applied to it in registers: two array passes per field instead
+// of the four of a separate kernel. Same expressions in the same order as mhh_rk_substep: the same bits.
 // SLAB: rows are the rank's own; the row south of the first strip belongs to the south neighbour, so vt of the rank's southernmost
 // row is left to mhh_pres_output_south_row (after the one-row halo of p), and p gets its x halo only (the y halo is the exchange's)
-template<class TF, int RG, int BT, int NX, bool SLAB = false>
+template<class TF, int RG, int BT, int NX, bool SLAB = false, bool RK = false>
 __global__ void __launch_bounds__(BT, (BT >= 128 ? 4 : 1)) pres_ifftx_out_kernel(const PresLdsOut<TF> a)
 {
     HIP_DYNAMIC_SHARED(LdsUnit, lds_raw);
@@ -664,10 +668,16 @@ __global__ void __launch_bounds__(BT, (BT >= 128 ? 4 : 1)) pres_ifftx_out_kernel
         for (int h=0; h<8; h+=RG)
         {
             TF tu[RG], tv[RG], tw[RG];
+            TF fu[RG], fv[RG], fw[RG];                                 // RK: the fields themselves
             if (emit)
             {
 #pragma unroll
                 for (int r=0; r<RG; ++r) { tu[r] = a.ut[c + (h+r)*jj]; tv[r] = a.vt[c + (h+r)*jj]; tw[r] = a.wt[c + (h+r)*jj]; }
+                if constexpr (RK)
+                {
+#pragma unroll
+                    for (int r=0; r<RG; ++r) { fu[r] = a.u[c + (h+r)*jj]; fv[r] = a.v[c + (h+r)*jj]; fw[r] = a.w[c + (h+r)*jj]; }
+                }
             }
 #pragma unroll
             for (int q=0; q<RG; ++q)
@@ -678,9 +688,19 @@ __global__ void __launch_bounds__(BT, (BT >= 128 ? 4 : 1)) pres_ifftx_out_kernel
                 {
                     const int cr = c + r*jj;
                     const TF pb = (k == 0) ? pc : below[r*itot];                          // p[kstart-1] = p[kstart]
-                    a.ut[cr] = tu[q] - (pc - pw) * g.dxi_t;
-                    if (has_south || r > 0) a.vt[cr] = tv[q] - (pc - ps) * g.dyi_t;
-                    a.wt[cr] = tw[q] - (pc - pb) * dzhi_k;
+                    const TF nut = tu[q] - (pc - pw) * g.dxi_t, nvt = tv[q] - (pc - ps) * g.dyi_t, nwt = tw[q] - (pc - pb) * dzhi_k;
+                    if constexpr (RK)
+                    {
+                        a.u[cr] = fu[q] + a.cB*a.rdt*nut; a.ut[cr] = a.cA*nut;
+                        a.v[cr] = fv[q] + a.cB*a.rdt*nvt; a.vt[cr] = a.cA*nvt;
+                        a.w[cr] = fw[q] + a.cB*a.rdt*nwt; a.wt[cr] = a.cA*nwt;
+                    }
+                    else
+                    {
+                        a.ut[cr] = nut;
+                        if (has_south || r > 0) a.vt[cr] = nvt;
+                        a.wt[cr] = nwt;
+                    }
                     // p: the cell, its images in the periodic halo, and the ghost level below the first one
                     const int js = j0 + r;
                     for (int lv=0; lv<2; ++lv)

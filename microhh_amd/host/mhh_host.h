@@ -456,6 +456,16 @@ class Pres
             mhh_grid g = grid.abi(); mhh_fields f = abi_fields(fields);
             mhh_check(mhh_pres_exec(plan, &g, &f, dt, stream));
         }
+        // pres->exec(sub_dt) and the momentum part of timeloop.exec() (src/model.cxx:411,484; src/timeloop.cxx:250-334) in one call:
+        // the sub-step of u, v, w is applied in the kernel that stores the corrected tendencies. The caller's Timeloop::exec then
+        // covers the scalars only. Same bits as exec() followed by the three sub-steps.
+        void exec_with_timeloop(double sub_dt, int rkorder, int substep, double dt, Stats&, void* stream = nullptr)
+        {
+            if (order == 0) return;
+            if (!plan) throw std::runtime_error("Pres::exec before prepare_device");
+            mhh_grid g = grid.abi(); mhh_fields f = abi_fields(fields);
+            mhh_check(mhh_pres_exec_rk(plan, &g, &f, sub_dt, rkorder, substep, dt, stream));
+        }
         TF check_divergence(void* stream = nullptr)
         {
             if (order == 0) return TF(0);                          // src/pres_disabled.cxx: check_divergence returns 0

@@ -435,6 +435,16 @@ class HotPath:
             self.halo([self.p])
             self._ok(lib.mhh_pres_output_order(self.G, 2, C.byref(self.fields), self.stream))
 
+    def pres_rk(self, rkorder, substep, dt):
+        """pres->exec(self.dt) followed by timeloop.exec() for u, v, w (src/model.cxx:411,484) with the sub-step applied in the
+        kernel that stores the corrected tendencies (mhh_pres_exec_rk); on a slab: pres() + three mhh_rk_substep calls."""
+        if not self.slab:
+            self._ok(self.lib.mhh_pres_exec_rk(self.plan, self.G, C.byref(self.fields), self.dt, rkorder, substep, dt, self.stream))
+            return
+        self.pres()
+        for a, at in ((self.u, self.ut), (self.v, self.vt), (self.w, self.wt)):
+            self._ok(self.lib.mhh_rk_substep(self.G, rkorder, substep, dt, a.data_ptr(), at.data_ptr(), self.stream))
+
     def _pres_sliced(self, packed, lds_x=False):
         """Pres_2::exec after the input stage, in k-slices: per slice x transform + pack, all-to-all on the exchange stream while
         the next slice is transformed, y transform as each slice arrives; Thomas sweeps over all levels; the same on the way back.

@@ -993,6 +993,37 @@ def test_rk_substep_bitexact(be, dtype):
             assert same(be.host(da), a) and same(be.host(dat), at), (order, sub)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("form", ["staged", "lds"])
+def test_pres_exec_with_the_rk_substep_in_its_last_kernel(be, form, dtype):
+    """mhh_pres_exec_rk = pres->exec(sub_dt) followed by timeloop.exec() for u, v, w (src/model.cxx:411,484) with the sub-step
+    applied in the kernel that stores the corrected tendencies: the bits of mhh_pres_exec + mhh_rk_substep x 3 in both forms of
+    Pres_2::exec, on every sub-step of RK3 and RK4 (the last one of a step and pres_4 take the separate kernels by themselves)."""
+    cases = [(2, cm.grid_2nd(16, 8, 6, gc=(3, 3, 1), dtype=dtype), "random"), (2, cm.grid_2nd(32, 16, 9, gc=(1, 1, 1), dtype=dtype), "random")]
+    if form == "staged":
+        cases += [(2, cm.grid_2nd(12, 10, 8, gc=(3, 3, 1), dtype=dtype), "random"), (4, cm.grid_4th(16, 12, 12, dtype=dtype), "one")]
+    for order, g, rho in cases:
+        c = cm.Case(g, rho=rho, periodic=True); Gh = g.host_struct(); dt, sub_dt = 0.31, 0.1
+        plan = capi.PLAN()
+        B.ok(be, be.lib.mhh_pres_plan_create(Gh, order, ptr(g.dz), ptr(g.dzhi), ptr(g.dzi4), ptr(g.dzhi4), ptr(c.rhoref), ptr(c.rhorefh), C.byref(plan)))
+        os.environ["MHH_PRES_LDS"] = "1" if form == "lds" else "0"
+        try:
+            for rko, nsub in ((3, 3), (4, 5)):
+                for sub in range(nsub):
+                    d1 = B.DevCase(be, c); f1 = d1.fields()
+                    B.ok(be, be.lib.mhh_pres_exec(plan, d1.G, C.byref(f1), sub_dt, be.stream))
+                    for a, at in ((d1.u, d1.ut), (d1.v, d1.vt), (d1.w, d1.wt)):
+                        B.ok(be, be.lib.mhh_rk_substep(d1.G, rko, sub, dt, be.ptr(a), be.ptr(at), be.stream))
+                    d2 = B.DevCase(be, c); f2 = d2.fields()
+                    B.ok(be, be.lib.mhh_pres_exec_rk(plan, d2.G, C.byref(f2), sub_dt, rko, sub, dt, be.stream))
+                    for nm in ("u", "v", "w", "ut", "vt", "wt", "p"):
+                        assert same(be.host(getattr(d1, nm)), be.host(getattr(d2, nm))), (form, order, g.shape3, rko, sub, nm)
+                    assert not same(be.host(d2.u), c.u)
+        finally:
+            os.environ.pop("MHH_PRES_LDS", None)
+            be.lib.mhh_pres_plan_destroy(plan)
+
+
 def test_errors_are_reported(be):
     g = cm.grid_2nd(16, 12, 10, gc=(1, 1, 1))
     c = cm.Case(g); d = B.DevCase(be, c)
