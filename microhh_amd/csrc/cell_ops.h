@@ -375,6 +375,26 @@ MHH_HD void advec4_mom_v(TF d[3], const FV& f, const UV& u, const VV& v, const W
     d[2] = ( cg0*advec4_pz<COMP,0,TF>(f, w, bot, top) + cg1*advec4_pz<COMP,1,TF>(f, w, bot, top)
            + cg2*advec4_pz<COMP,2,TF>(f, w, bot, top) + cg3*advec4_pz<COMP,3,TF>(f, w, bot, top) ) * dz;
 }
+// The same with the VERTICAL face products carried from level to level by a k-marching kernel (k_march4.hip): product M of level
+// k+1 is product M+1 of level k -- same operands, same order -- so a level forms only its topmost product (M = 3) and takes the
+// other three from the level below (c[0..2]); `fresh` (the first level a thread works, and the levels whose lowest product is the
+// biased wall form) forms all four. Fifteen operations and four LDS reads per reused product of the u and v equations, eight
+// for w. The sum and its order are advec4_mom_v's: the same bits.
+template<int COMP, class TF, class FV, class UV, class VV, class WV>
+MHH_HD void advec4_mom_vc(TF d[3], const FV& f, const UV& u, const VV& v, const WV& w, bool bot, bool top, TF dxi, TF dyi, TF dz, bool dim3, TF (&c)[3], bool fresh)
+{
+    const TF cg0 = TF(1./24.), cg1 = TF(-27./24.), cg2 = TF(27./24.), cg3 = TF(-1./24.);
+    d[0] = ( cg0*advec4_px<COMP,0,TF>(f, u) + cg1*advec4_px<COMP,1,TF>(f, u) + cg2*advec4_px<COMP,2,TF>(f, u) + cg3*advec4_px<COMP,3,TF>(f, u) ) * dxi;
+    d[1] = TF(0);
+    if (dim3)
+        d[1] = ( cg0*advec4_py<COMP,0,TF>(f, v) + cg1*advec4_py<COMP,1,TF>(f, v) + cg2*advec4_py<COMP,2,TF>(f, v) + cg3*advec4_py<COMP,3,TF>(f, v) ) * dyi;
+    TF p0, p1, p2;
+    if (fresh) { p0 = advec4_pz<COMP,0,TF>(f, w, bot, top); p1 = advec4_pz<COMP,1,TF>(f, w, bot, top); p2 = advec4_pz<COMP,2,TF>(f, w, bot, top); }
+    else       { p0 = c[0]; p1 = c[1]; p2 = c[2]; }
+    const TF p3 = advec4_pz<COMP,3,TF>(f, w, bot, top);
+    d[2] = ( cg0*p0 + cg1*p1 + cg2*p2 + cg3*p3 ) * dz;
+    c[0] = p1; c[1] = p2; c[2] = p3;
+}
 // advec_4m (src/advec_4m.cxx:90-478): every term is grad4 over four face products, each the 4th-order interpolated
 // advecting velocity times a TWO-point mean of the advected quantity over a widening stencil ((-3,0), (-1,0), (0,1), (0,3)
 // cells along the direction); at the walls the outermost vertical product is the mirrored one. One increment per cell.
@@ -519,6 +539,33 @@ MHH_HD void diff4_v(TF d[3], const AV& a, bool bot, bool top, TF visc, TF dxidxi
                   + cg1*cg4<TF>(a.template at<0,0,-2>(), a.template at<0,0,-1>(), a.template at<0,0,0>(), a.template at<0,0,1>()) * g4[1]
                   + cg2*cg4<TF>(a.template at<0,0,-1>(), a.template at<0,0,0>(), a.template at<0,0,1>(), a.template at<0,0,2>()) * g4[2]
                   + cg3*g3 * g4[3] ) * go;
+}
+// diff4_v with the inner vertical gradients carried from level to level (see advec4_mom_vc): gradient M of level k+1 is gradient
+// M+1 of level k; seven operations per reused gradient
+template<class TF, class AV>
+MHH_HD void diff4_vc(TF d[3], const AV& a, bool bot, bool top, TF visc, TF dxidxi, TF dyidyi, const TF g4[4], TF go, bool dim3, TF (&c)[3], bool fresh)
+{
+    const TF cdg0 = TF(-1460./576.), cdg1 = TF(783./576.), cdg2 = TF(-54./576.), cdg3 = TF(1./576.);
+    const TF cg0 = TF(1./24.), cg1 = TF(-27./24.), cg2 = TF(27./24.), cg3 = TF(-1./24.);
+    d[0] = visc * (cdg3*a.template at<-3,0,0>() + cdg2*a.template at<-2,0,0>() + cdg1*a.template at<-1,0,0>() + cdg0*a.template at<0,0,0>()
+                 + cdg1*a.template at<1,0,0>() + cdg2*a.template at<2,0,0>() + cdg3*a.template at<3,0,0>())*dxidxi;
+    d[1] = TF(0);
+    if (dim3)
+        d[1] = visc * (cdg3*a.template at<0,-3,0>() + cdg2*a.template at<0,-2,0>() + cdg1*a.template at<0,-1,0>() + cdg0*a.template at<0,0,0>()
+                     + cdg1*a.template at<0,1,0>() + cdg2*a.template at<0,2,0>() + cdg3*a.template at<0,3,0>())*dyidyi;
+    TF g0, g1, g2;
+    if (fresh)
+    {
+        g0 = bot ? bg4<TF>(a.template at<0,0,-2>(), a.template at<0,0,-1>(), a.template at<0,0,0>(), a.template at<0,0,1>())
+                 : cg4<TF>(a.template at<0,0,-3>(), a.template at<0,0,-2>(), a.template at<0,0,-1>(), a.template at<0,0,0>());
+        g1 = cg4<TF>(a.template at<0,0,-2>(), a.template at<0,0,-1>(), a.template at<0,0,0>(), a.template at<0,0,1>());
+        g2 = cg4<TF>(a.template at<0,0,-1>(), a.template at<0,0,0>(), a.template at<0,0,1>(), a.template at<0,0,2>());
+    }
+    else { g0 = c[0]; g1 = c[1]; g2 = c[2]; }
+    const TF g3 = top ? tg4<TF>(a.template at<0,0,-1>(), a.template at<0,0,0>(), a.template at<0,0,1>(), a.template at<0,0,2>())
+                      : cg4<TF>(a.template at<0,0,0>(), a.template at<0,0,1>(), a.template at<0,0,2>(), a.template at<0,0,3>());
+    d[2] = visc * ( cg0*g0 * g4[0] + cg1*g1 * g4[1] + cg2*g2 * g4[2] + cg3*g3 * g4[3] ) * go;
+    c[0] = g1; c[1] = g2; c[2] = g3;
 }
 template<class TF>
 MHH_HD void diff4_cell(TF d[3], const TF* __restrict__ a, int c, int jj, int kk, bool bot, bool top, TF visc,

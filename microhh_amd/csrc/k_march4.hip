@@ -121,8 +121,17 @@ __global__ void __launch_bounds__(64*NJ, MHH_MARCH4_OCC) rhs44_march_kernel(cons
     // the u and v results of level k are stored at the top of iteration k+1: the s_waitcnt vmcnt(0) in front of the
     // end-of-level barrier also waits for stores, and stores issued right before it would expose their latency
     TF ut_pending = 0, vt_pending = 0; int c_pending = -1;
+    // vertical face products of the advection and inner vertical gradients of the diffusion, carried to the next level
+    // (cell_ops.h, advec4_mom_vc / diff4_vc; MHH_MARCH4_CARRY=0: every level forms all four, as the cell kernels do)
+#ifndef MHH_MARCH4_CARRY
+#define MHH_MARCH4_CARRY 1
+#endif
+    constexpr bool CARRY = (MHH_MARCH4_CARRY != 0);
+    TF au[3] = {0, 0, 0}, av[3] = {0, 0, 0}, aw[3] = {0, 0, 0}, du[3] = {0, 0, 0}, dv[3] = {0, 0, 0}, dw[3] = {0, 0, 0};
+    const int kw0 = (kb > g.kstart) ? kb : g.kstart + 1;            // the first level of this chunk with a w equation
     for (int k = kb; k < ke; ++k)
     {
+        const bool fresh = !CARRY || (k == kb), fresh_w = !CARRY || (k == kw0);
         const bool more = (k + 1 < ke);
         if (more) dma_tile(f.w, k+3, W[sw(k+3)]);
         if (c_pending >= 0) { stream_store(f.ut + c_pending, ut_pending); stream_store(f.vt + c_pending, vt_pending); c_pending = -1; }
@@ -142,8 +151,8 @@ __global__ void __launch_bounds__(64*NJ, MHH_MARCH4_OCC) rhs44_march_kernel(cons
         {
             const bool botw = (k == g.kstart+1);
             const TF gw4[4] = {uniform_load(g.dzi4, k-2), uniform_load(g.dzi4, k-1), uniform_load(g.dzi4, k), uniform_load(g.dzi4, k+1)};
-            if constexpr (ADV) advec4_mom_v<2>(ad, Wv, Uv, Vv, Wv, botw, top, dxi, dyi, uniform_load(g.dzhi4, k), dim3);
-            if constexpr (DIF) diff4_v(df, Wv, botw, top, f.visc, g.dxidxi_t, g.dyidyi_t, gw4, uniform_load(g.dzhi4, k), dim3);
+            if constexpr (ADV) advec4_mom_vc<2>(ad, Wv, Uv, Vv, Wv, botw, top, dxi, dyi, uniform_load(g.dzhi4, k), dim3, aw, fresh_w);
+            if constexpr (DIF) diff4_vc(df, Wv, botw, top, f.visc, g.dxidxi_t, g.dyidyi_t, gw4, uniform_load(g.dzhi4, k), dim3, dw, fresh_w);
             stream_store(f.wt + c, both(TPREF ? tcw : stream_load(f.wt + c), ad, df));
         }
         if (more)
@@ -155,11 +164,11 @@ __global__ void __launch_bounds__(64*NJ, MHH_MARCH4_OCC) rhs44_march_kernel(cons
         if (active)
         {
             const TF gc4[4] = {uniform_load(g.dzhi4, k-1), uniform_load(g.dzhi4, k), uniform_load(g.dzhi4, k+1), uniform_load(g.dzhi4, k+2)};
-            if constexpr (ADV) advec4_mom_v<0>(ad, Uv, Uv, Vv, Wv, bot, top, dxi, dyi, uniform_load(g.dzi4, k), dim3);
-            if constexpr (DIF) diff4_v(df, Uv, bot, top, f.visc, g.dxidxi_d, g.dyidyi_d, gc4, uniform_load(g.dzi4, k), dim3);
+            if constexpr (ADV) advec4_mom_vc<0>(ad, Uv, Uv, Vv, Wv, bot, top, dxi, dyi, uniform_load(g.dzi4, k), dim3, au, fresh);
+            if constexpr (DIF) diff4_vc(df, Uv, bot, top, f.visc, g.dxidxi_d, g.dyidyi_d, gc4, uniform_load(g.dzi4, k), dim3, du, fresh);
             ut_pending = both(TPREF ? tcu : stream_load(f.ut + c), ad, df);
-            if constexpr (ADV) advec4_mom_v<1>(ad, Vv, Uv, Vv, Wv, bot, top, dxi, dyi, uniform_load(g.dzi4, k), dim3);
-            if constexpr (DIF) diff4_v(df, Vv, bot, top, f.visc, g.dxidxi_d, g.dyidyi_d, gc4, uniform_load(g.dzi4, k), dim3);
+            if constexpr (ADV) advec4_mom_vc<1>(ad, Vv, Uv, Vv, Wv, bot, top, dxi, dyi, uniform_load(g.dzi4, k), dim3, av, fresh);
+            if constexpr (DIF) diff4_vc(df, Vv, bot, top, f.visc, g.dxidxi_d, g.dyidyi_d, gc4, uniform_load(g.dzi4, k), dim3, dv, fresh);
             vt_pending = both(TPREF ? tcv : stream_load(f.vt + c), ad, df);
             c_pending = c;
         }
