@@ -43,5 +43,8 @@ def test_fma_build_within_stated_tolerance(shape):
         err = np.abs((b - a)[it]).max() / np.spacing(scale)
         worst = max(worst, err)
         assert err <= TOL_ULP, (shape, nm, err)
-        assert not np.array_equal(a, b) or True            # (they may coincide on tiny grids; nothing to assert)
+    # the named build must BE a different build: on a grid of this size contraction changes the last bits of some tendency (if the
+    # link step had silently produced the bit-exact objects the tolerance check above would pass trivially)
+    if shape[0]*shape[1]*shape[2] >= 128*64*140:
+        assert any(not np.array_equal(a, b) for a, b in zip(out["exact"], out["fma"])), "the FMA library gives the bit-exact build's bits"
     print("fma build: worst deviation %.1f ulp of the largest increment (stated tolerance %g)" % (worst, TOL_ULP))
