@@ -104,7 +104,14 @@ template<class TF> struct alignas(16) MarchMetrics
 __device__ __forceinline__ void mfence() { if constexpr (MHH_MARCH_FENCE != 0) sched_fence(); }
 // (0.25 arrives as a scalar operand and c in a vector register: a VOP3 instruction takes one scalar register operand and no 32-bit
 // literal on gfx9, and 0.25 is not an inline constant -- with both as scalars the compiler emitted v_mov + v_fmac, no saving)
-template<class VT, class TF> __device__ __forceinline__ VT quarter_plus(VT x, TF quarter, VT c) { return tfma(x, VT(quarter), c); }
+template<class VT, class TF> __device__ __forceinline__ VT quarter_plus(VT x, TF quarter, VT c)
+{
+#ifndef MHH_MARCH_QP_F2
+    if constexpr (lane_of<VT>::cells == 2) return TF(0.25)*x + c;        // two cells per lane: packed multiply + packed add (the fma form unpacks)
+    else
+#endif
+    return tfma(x, VT(quarter), c);
+}
 
 
 template<class TF> struct MarchFields
@@ -235,6 +242,11 @@ rhs25_march_kernel(const MarchMetrics<typename lane_of<VT>::scalar> mm, const Gr
     auto adv = [&](const TF* q, int n) -> const TF* { return reinterpret_cast<const TF*>(reinterpret_cast<const char*>(q) + n*kk8); };
     // the uniform coefficients: read per level from the kernel-argument segment (see MarchMetrics)
     const TF* const kmm = first_kernarg(reinterpret_cast<const TF&>(mm));
+#ifdef MHH_MARCH_F2_PINNED     // experiment: two-cells-per-lane form with the coefficients pinned in scalar registers as in round 2
+    Uniform8<TF> pin0, pin1;
+    pin0.v[0] = sgpr(mm.dxih); pin0.v[1] = sgpr(mm.dyih); pin0.v[2] = sgpr(mm.dxd); pin0.v[3] = sgpr(mm.dyd); pin0.v[4] = sgpr(mm.dxd2); pin0.v[5] = sgpr(mm.dyd2); pin0.v[6] = sgpr(mm.visc); pin0.v[7] = sgpr(mm.quarter);
+    pin1.v[0] = sgpr(mm.dxi); pin1.v[1] = sgpr(mm.dyi); pin1.v[2] = sgpr(mm.dxidxi); pin1.v[3] = sgpr(mm.dyidyi); pin1.v[4] = sgpr(mm.svisc); pin1.v[5] = sgpr(mm.tPr2); pin1.v[6] = sgpr(mm.rtPr2); pin1.v[7] = TF(0);
+#endif
     const TF* __restrict__ tdzi = sgpr(g.dzi); const TF* __restrict__ tdzhi = sgpr(g.dzhi);
 
     // ---- tile movers. A tile is walked in pieces of PW 32-bit words: e = tid + n*NT; piece -> (row, first word) --------
@@ -391,7 +403,11 @@ rhs25_march_kernel(const MarchMetrics<typename lane_of<VT>::scalar> mm, const Gr
         // ring slot of plane k+d: inside a rotated group k - kg0 = ROT (mod 6), a constant for the rings whose depth divides 6
         auto sl = [&](int d, int r) { return (ROT >= 0 && 6 % r == 0) ? (ROT + d + 12) % r : slot(k + d, r); };
         const TF* const mq = sgpr(kmm);                          // opaque per level: the loads stay inside the level
+#ifdef MHH_MARCH_F2_PINNED
+        const Uniform8<TF> mg0 = (CW == 2) ? pin0 : uniform_load8(mq);
+#else
         const Uniform8<TF> mg0 = uniform_load8(mq);
+#endif
         const TF dxih = mg0.v[0], dyih = mg0.v[1], dxd = mg0.v[2], dyd = mg0.v[3], dxd2 = mg0.v[4], dyd2 = mg0.v[5], visc = mg0.v[6], quarter = mg0.v[7];
         VT viscv = VT(visc); if constexpr (CW == 1) pin_vgpr(viscv); else pin_vgpr(viscv.v);                    // the viscosity once per level in a vector register (quarter_plus)
         MHH_STAMP(4);                                             // (loop control, window rotation: since the last barrier)
@@ -419,7 +435,8 @@ rhs25_march_kernel(const MarchMetrics<typename lane_of<VT>::scalar> mm, const Gr
 #ifndef MHH_MARCH_SPREAD
 #define MHH_MARCH_SPREAD 1
 #endif
-        constexpr int SPREAD = (sizeof(VT) == 8) ? MHH_MARCH_SPREAD : 0;
+        // (fp64 only: the two-cells-per-lane fp32 form measured 5.53 ms spread against 5.18 ms with all copies at the top, gabls1 1024 x 1024 x 256)
+        constexpr int SPREAD = (sizeof(TF) == 8) ? MHH_MARCH_SPREAD : 0;
         auto copies_at = [&](int pos) __attribute__((always_inline))
         {
             constexpr int where[3][3] = { {0, 0, 0}, {0, 1, 2}, {1, 2, 2} };
@@ -624,7 +641,11 @@ rhs25_march_kernel(const MarchMetrics<typename lane_of<VT>::scalar> mm, const Gr
                 // every level (the next level carries it), the tendency on updating levels
                 if constexpr (HAS_S)
                 {
-                    const Uniform8<TF> mg1 = uniform_load8(mq + 8);
+        #ifdef MHH_MARCH_F2_PINNED
+            const Uniform8<TF> mg1 = (CW == 2) ? pin1 : uniform_load8(mq + 8);
+#else
+            const Uniform8<TF> mg1 = uniform_load8(mq + 8);
+#endif
                     const TF dxi = mg1.v[0], dyi = mg1.v[1], dxidxi = mg1.v[2], dyidyi = mg1.v[3], svisc = mg1.v[4], tPr2 = mg1.v[5], rtPr2 = mg1.v[6];
                     auto div_tpr = [&](VT x) -> VT { return div_known(x, tPr2, rtPr2); };     // 0.5*x / tPr
                     if (DIF && need_dtop)
@@ -681,11 +702,13 @@ rhs25_march_kernel(const MarchMetrics<typename lane_of<VT>::scalar> mm, const Gr
         // ---- carry the top faces down, rotate the windows, advance the plane pointers ------------------------------------
         cTu = Tu; cGu = Gu; cDu = Du; cTv = Tv; cGv = Gv; cDv = Dv; cTw = Tw; cGw = Gw; cDw = Dw; cTs = Ts; cGs = Gs; cDs = Ds;
         u1m = u_e; vNm = v_n;
+        // (opaque after the add: as recognisable induction variables the compiler keeps the loop-invariant START values and one
+        //  running scalar instead -- and under register pressure parks the start values in scratch, a scratch_load + vmcnt(0) per use)
 #pragma unroll
-        for (int n=0; n<NLD; ++n) off[n] += kk8w;
+        for (int n=0; n<NLD; ++n) { off[n] += kk8w; keep_vgpr(off[n]); }
 #pragma unroll
-        for (int n=0; n<NLDE; ++n) offe[n] += kk8w;
-        bo0 += kk8w;
+        for (int n=0; n<NLDE; ++n) { offe[n] += kk8w; keep_vgpr(offe[n]); }
+        bo0 += kk8w; keep_vgpr(bo0);
         // unconditional (also after the chunk's last level, where nothing is in flight): every path back to the loop head
         // then carries a vmcnt(0) the compiler can see, and it inserts no wait of its own in the next level
         MHH_STAMP(1);                                          // the level's arithmetic, LDS reads, stores
