@@ -799,6 +799,7 @@ int march_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* 
 #endif
     // a strip of a few rows (mhh_rhs_exec_rows on the edge rows) takes short k-chunks: enough blocks to fill the GPU
     int kc = (j0 >= 0 && (j1 - j0 + (j2 >= 0 ? j3 - j2 : 0)) * 4 <= g->jmax) ? 16 : MHH_MARCH_KC;
+    { const char* e = getenv("MHH_MARCH_KC_RT"); if (e && atoi(e) >= 8) kc = atoi(e); }       // tuning runs: levels per chunk at run time
     // the lanes address a chunk's planes with 32-bit byte offsets from the chunk's first plane: (kc + 8) planes below 4 GB
     const unsigned long long plane_bytes = (unsigned long long)g->ijcells * sizeof(TF);
     while (kc > 8 && (unsigned long long)(kc + 8) * plane_bytes >= (1ull << 32)) kc /= 2;

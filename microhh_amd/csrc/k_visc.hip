@@ -171,7 +171,8 @@ int visc_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p
     vf.dudz = cp<TF>(f->dudz); vf.dvdz = cp<TF>(f->dvdz); vf.dbdz = cp<TF>(f->dbdz); vf.z0m = cp<TF>(f->z0m);
     vf.N2 = cp<TF>(p->N2); vf.th = cp<TF>(th); vf.thref = cp<TF>(p->thref); vf.mlen0 = cp<TF>(p->mlen0); vf.mlen2 = cp<TF>(p->mlen2);
     vf.grav = TF(p->grav); vf.tPr = TF(p->tPr); vf.sm = p->surface_model; vf.neutral = p->neutral; vf.ex = ex;
-    const int kc = (j0 >= 0 && (j1 - j0 + (j2 >= 0 ? j3 - j2 : 0)) * 4 <= g->jmax) ? 16 : MHH_VISC_KC;      // few rows: short k-chunks fill the GPU
+    int kc = (j0 >= 0 && (j1 - j0 + (j2 >= 0 ? j3 - j2 : 0)) * 4 <= g->jmax) ? 16 : MHH_VISC_KC;      // few rows: short k-chunks fill the GPU
+    { const char* e = getenv("MHH_VISC_KC_RT"); if (e && atoi(e) >= 8) kc = atoi(e); }         // tuning runs
     const MarchTiling t = make_march_tiling(g, NJ, kc, j0, j1, 64, j2, j3);
     const dim3 nb(march_blocks(t)), bs(64, NJ);
     const GridDev<TF> gd = make_grid<TF>(g);
