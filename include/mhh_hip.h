@@ -348,6 +348,12 @@ int mhh_pres_unpack_output_slab(mhh_pres_slab_plan* plan, const mhh_grid* g, con
 int mhh_pres_slab_has_lds(const mhh_pres_slab_plan* plan);
 int mhh_pres_slab_lds_fwd(mhh_pres_slab_plan* plan, const mhh_grid* g, const mhh_fields* f, double dt, void* sendbuf, int c, void* stream);
 int mhh_pres_slab_lds_bwd(mhh_pres_slab_plan* plan, const mhh_grid* g, const void* recvbuf, const mhh_fields* f, int c, void* stream);
+/* the y stage of that form: the all-to-all buffers are laid out [slice][peer][k][kxl][row] (rows fastest: a column's rows from one rank
+ * are one run), so the transforms along y read / write them directly (src/fft.cxx:499-538) around the Thomas sweeps (mhh_pres_solve_y).
+ * Call order per solve: for c: lds_fwd(c) -> all-to-all(c);  for c: lds_fwd_y(c);  solve_y;  for c: lds_bwd_y(c) -> all-to-all(c);
+ * for c: lds_bwd(c);  p halo (one row);  output_south_row. */
+int mhh_pres_slab_lds_fwd_y(mhh_pres_slab_plan* plan, const mhh_grid* g, void* recvbuf, int c, void* stream);
+int mhh_pres_slab_lds_bwd_y(mhh_pres_slab_plan* plan, const mhh_grid* g, void* sendbuf, int c, void* stream);
 
 /* ---- Vertical ghost cells --------------------------------------------------------------
  * Boundary::set_ghost_cells: calc_ghost_cells_{bot,top}_{2nd,4th} (src/boundary.cxx:686-836); bc 0 = Dirichlet

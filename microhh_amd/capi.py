@@ -119,6 +119,8 @@ SIGNATURES = {
     "mhh_pres_slab_has_lds": (ci, [PLAN]),
     "mhh_pres_slab_lds_fwd": (ci, [PLAN, GP, FP, C.c_double, vp, ci, vp]),
     "mhh_pres_slab_lds_bwd": (ci, [PLAN, GP, vp, FP, ci, vp]),
+    "mhh_pres_slab_lds_fwd_y": (ci, [PLAN, GP, vp, ci, vp]),
+    "mhh_pres_slab_lds_bwd_y": (ci, [PLAN, GP, vp, ci, vp]),
 }
 
 

@@ -1084,6 +1084,25 @@ static int lds_slab_kernels_ready(int itot, bool& usable)
     }
     return MHH_OK;
 }
+template<class TF>
+static int lds_slab_y_ready(int jtot, bool& usable)
+{
+    const int ny = ilog2(jtot);
+    const void* k[2] = {nullptr, nullptr};
+    if (jtot <= LDS_YS) { k[0] = reinterpret_cast<const void*>(&lds_fft::slab_yfft_kernel<TF, LDS_YS, 0, true>); k[1] = reinterpret_cast<const void*>(&lds_fft::slab_yfft_kernel<TF, LDS_YS, 0, false>); }
+#define M(N) if (ny == N) { if constexpr (lds_has_ny<TF, N>()) { k[0] = reinterpret_cast<const void*>(&lds_fft::slab_yfft_kernel<TF, (1 << N), N, true>); k[1] = reinterpret_cast<const void*>(&lds_fft::slab_yfft_kernel<TF, (1 << N), N, false>); } }
+    MHH_FOR_NY(M)
+#undef M
+    usable = true;
+    for (int n=0; n<2; ++n)
+    {
+        if (!k[n]) { usable = false; return MHH_OK; }
+        bool u = false;
+        if (int e = lds_kernel_ready(k[n], u)) return e;
+        usable = usable && u;
+    }
+    return MHH_OK;
+}
 static size_t lds_slab_bytes_x(int itot, size_t esz, int rows) { return ((size_t)rows*(itot/2 + 2) + itot) * 2*esz + (rows == 9 ? (size_t)8*itot*esz : 0); }
 // 1 if a rank of this grid can run the x stages in LDS: power-of-two itot with an instantiation, rows in whole strips of eight
 int lds_slab_usable(const mhh_grid* g)
@@ -1091,9 +1110,12 @@ int lds_slab_usable(const mhh_grid* g)
     if (!(is_pow2(g->itot) && g->itot >= 16 && g->itot <= 1024 && g->jmax % 8 == 0 && g->jmax >= 8)) return 0;
     if (lds_slab_bytes_x(g->itot, g->dtype == MHH_F64 ? 8 : 4, 9) > 160*1024 || g->igc > g->itot) return 0;
     if ((long long)g->icells*g->jcells*g->kcells >= (1ll << 31)) return 0;
-    bool usable = false;
-    const int e = (g->dtype == MHH_F64) ? lds_slab_kernels_ready<double>(g->itot, usable) : lds_slab_kernels_ready<float>(g->itot, usable);
-    return (e == MHH_OK && usable) ? 1 : 0;
+    if (!(is_pow2(g->jtot) && g->jtot >= 8 && g->jtot <= 1024 && g->jtot % g->jmax == 0)) return 0;
+    if (((size_t)8*g->jtot + g->jtot) * 2*(g->dtype == MHH_F64 ? 8 : 4) > 160*1024) return 0;
+    bool usable = false, usable_y = false;
+    int e = (g->dtype == MHH_F64) ? lds_slab_kernels_ready<double>(g->itot, usable) : lds_slab_kernels_ready<float>(g->itot, usable);
+    if (e == MHH_OK) e = (g->dtype == MHH_F64) ? lds_slab_y_ready<double>(g->jtot, usable_y) : lds_slab_y_ready<float>(g->jtot, usable_y);
+    return (e == MHH_OK && usable && usable_y) ? 1 : 0;
 }
 // exp(-2 pi i m / itot), m < itot, on the device (the caller frees it)
 int lds_slab_twiddles(const mhh_grid* g, void** tx)
@@ -1104,6 +1126,35 @@ int lds_slab_twiddles(const mhh_grid* g, void** tx)
                                t[0] = 1; t[1] = 0; t[n] = -1; t[n+1] = 0; if (n >= 4) { t[n/2] = 0; t[n/2+1] = -1; t[3*n/2] = 0; t[3*n/2+1] = 1; } };
     if (g->dtype == MHH_F64) { std::vector<double> t(2*(size_t)n); fill(t.data()); return upload(tx, t); }
     std::vector<float> t(2*(size_t)n); fill(t.data()); return upload(tx, t);
+}
+// exp(-2 pi i m / jtot), m < jtot
+int lds_slab_twiddles_y(const mhh_grid* g, void** ty)
+{
+    const double pi = std::acos(-1.);
+    const int n = g->jtot;
+    auto fill = [&](auto* t) { for (int m=0; m<n; ++m) { t[2*m] = std::cos(2.*pi*m/n); t[2*m+1] = -std::sin(2.*pi*m/n); }
+                               t[0] = 1; t[1] = 0; t[n] = -1; t[n+1] = 0; if (n >= 4) { t[n/2] = 0; t[n/2+1] = -1; t[3*n/2] = 0; t[3*n/2+1] = 1; } };
+    if (g->dtype == MHH_F64) { std::vector<double> t(2*(size_t)n); fill(t.data()); return upload(ty, t); }
+    std::vector<float> t(2*(size_t)n); fill(t.data()); return upload(ty, t);
+}
+// the transforms along y of the levels [kbeg, kend): forward from the receive buffer into specy[k][kxl][ky], or back from specy into the send buffer
+int lds_slab_yfft(const mhh_grid* g, bool fwd, void* xbuf, void* specy, const void* ty, int nxb, int npy, int ks, int kbeg, int kend, hipStream_t st)
+{
+    const int ny = ilog2(g->jtot);
+    const dim3 grid((unsigned)nxb, (unsigned)((kend - kbeg + 7)/8)), block((unsigned)g->jtot);
+    const size_t lds = ((size_t)8*g->jtot + g->jtot) * 2*(g->dtype == MHH_F64 ? 8 : 4);
+#define M(TF, N) else if (ny == N) { if constexpr (lds_has_ny<TF, N>()) { \
+                     if (fwd) hipLaunchKernelGGL((lds_fft::slab_yfft_kernel<TF, (1 << N), N, true>), grid, block, lds, st, a); \
+                     else     hipLaunchKernelGGL((lds_fft::slab_yfft_kernel<TF, (1 << N), N, false>), grid, block, lds, st, a); } }
+#define CALL(TF) [&]{ lds_fft::SlabYfft<TF> a{static_cast<C2<TF>*>(xbuf), static_cast<C2<TF>*>(specy), static_cast<const C2<TF>*>(ty), g->jtot, g->jmax, ny, nxb, kbeg, kend, {nxb, npy, ks}}; \
+                      if (g->jtot <= LDS_YS) { if (fwd) hipLaunchKernelGGL((lds_fft::slab_yfft_kernel<TF, LDS_YS, 0, true>), grid, block, lds, st, a); \
+                                               else     hipLaunchKernelGGL((lds_fft::slab_yfft_kernel<TF, LDS_YS, 0, false>), grid, block, lds, st, a); } \
+                      MHH_FOR_NY_T(M, TF) return MHH_OK; }()
+    if (int e = MHH_DISPATCH(g, CALL)) return e;
+#undef CALL
+#undef M
+    MHH_LAUNCH_CHECK();
+    return MHH_OK;
 }
 static int lds_slab_kc(const mhh_grid* g, int nlev)
 {

@@ -112,7 +112,7 @@ struct mhh_pres_slab_plan
     rocfft_execution_info info = nullptr;
     void* wb = nullptr; size_t wbs = 0, wb_cap = 0;
     // the x stages with the transforms in LDS (pres_lds.h, pres_lds_slab.h): twiddles exp(-2 pi i m / itot); null = not available
-    void* tx_lds = nullptr;
+    void* tx_lds = nullptr; void* ty_lds = nullptr;
 };
 
 template<class TF>
@@ -168,6 +168,7 @@ static int plan1d(rocfft_plan* plan, rocfft_transform_type type, rocfft_result_p
 MHH_API void mhh_pres_slab_plan_destroy(mhh_pres_slab_plan* P)
 {
     if (P && P->tx_lds) { (void)hipFree(P->tx_lds); P->tx_lds = nullptr; }
+    if (P && P->ty_lds) { (void)hipFree(P->ty_lds); P->ty_lds = nullptr; }
     if (!P) return;
     for (rocfft_plan p : {P->fx, P->bx, P->fy, P->by, P->cfx, P->cbx, P->cfy, P->cby}) if (p) rocfft_plan_destroy(p);
     if (P->info) rocfft_execution_info_destroy(P->info);
@@ -209,7 +210,7 @@ MHH_API int mhh_pres_slab_plan_create(const mhh_grid* g, const void* host_dz, co
         }
     }
     if (!e) e = slab_factor(P);
-    if (!e && lds_slab_usable(g)) e = lds_slab_twiddles(g, &P->tx_lds);      // the x stages with the transforms in LDS
+    if (!e && lds_slab_usable(g)) { e = lds_slab_twiddles(g, &P->tx_lds); if (!e) e = lds_slab_twiddles_y(g, &P->ty_lds); }      // the transforms in LDS
     if (e) { mhh_pres_slab_plan_destroy(P); return e; }
     *out = P;
     return MHH_OK;
@@ -764,6 +765,23 @@ MHH_API int mhh_pres_slab_lds_bwd(mhh_pres_slab_plan* P, const mhh_grid* g, cons
     MHH_REQUIRE(c >= 0 && c < P->nchunks, "k-slice");
     const int ks = P->ktot / P->nchunks;
     return lds_slab_stage_out(g, f, recvbuf, P->tx_lds, P->nxb, P->npy, ks, c*ks, (c+1)*ks, as_stream(stream));
+}
+// The y stage of the LDS form: the transform along y of k-slice c from the receive buffer into the plan's [k][kxl][ky] array
+// (mhh_pres_slab_lds_fwd_y), the Thomas sweeps over all levels (mhh_pres_solve_y), the transform back into the send buffer
+// (mhh_pres_slab_lds_bwd_y). The buffers of this form are laid out [slice][peer][k][kxl][row] (rows fastest), NOT as the staged form's.
+MHH_API int mhh_pres_slab_lds_fwd_y(mhh_pres_slab_plan* P, const mhh_grid* g, void* recvbuf, int c, void* stream)
+{
+    if (int e = slab_match(P, g)) return e;
+    MHH_REQUIRE(P->ty_lds != nullptr && recvbuf && c >= 0 && c < P->nchunks, "LDS form, buffer, k-slice");
+    const int ks = P->ktot / P->nchunks;
+    return lds_slab_yfft(g, true, recvbuf, P->specy, P->ty_lds, P->nxb, P->npy, ks, c*ks, (c+1)*ks, as_stream(stream));
+}
+MHH_API int mhh_pres_slab_lds_bwd_y(mhh_pres_slab_plan* P, const mhh_grid* g, void* sendbuf, int c, void* stream)
+{
+    if (int e = slab_match(P, g)) return e;
+    MHH_REQUIRE(P->ty_lds != nullptr && sendbuf && c >= 0 && c < P->nchunks, "LDS form, buffer, k-slice");
+    const int ks = P->ktot / P->nchunks;
+    return lds_slab_yfft(g, false, sendbuf, P->specy, P->ty_lds, P->nxb, P->npy, ks, c*ks, (c+1)*ks, as_stream(stream));
 }
 // all slices back: unpack + Pres_2::output in one kernel (the tail of mhh_pres_bwd_x_unpack_output)
 MHH_API int mhh_pres_unpack_output_slab(mhh_pres_slab_plan* P, const mhh_grid* g, const mhh_fields* f, void* stream)

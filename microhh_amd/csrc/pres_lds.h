@@ -202,15 +202,17 @@ __device__ __forceinline__ void lds_strip_of_block(int nstrips, int& strip, int&
 }
 
 // Slab-decomposed grids (npx = 1, npy = N; k_slab.hip): the x-stage kernels work on the rank's own rows and talk to the
-// all-to-all buffers of the x <-> y transpose directly (src/transpose.cxx:170-219): layout [slice][peer q][k in slice][row][kxl],
-// kx = q*nxb + kxl, the itot/2 + 1 modes unpacked (the Nyquist mode in a column of its own, as the y stage of k_slab.hip expects)
-// and padded with zeros to npy*nxb columns. A thread then handles one MODE of a row (consecutive threads = consecutive modes: runs
-// of nxb complex numbers per peer) instead of one row of a mode.
+// all-to-all buffers of the x <-> y transpose directly (src/transpose.cxx:170-219): layout [slice][peer q][k in slice][kxl][row],
+// kx = q*nxb + kxl, the itot/2 + 1 modes unpacked (the Nyquist mode in a column of its own: every column is an ordinary complex
+// column for the y stage) and padded with zeros to npy*nxb columns. The y stage of this form is slab_yfft_kernel below + the Thomas
+// sweeps of k_slab.hip.
 struct LdsSlab { int nxb, npy, ks; };                    // modes per peer, peers, levels per slice
+// [slice][peer q][k in slice][kxl][row]: rows fastest, like S[k][kx][j] of the single-GPU form -- the x stages store / load eight
+// rows of a mode as one 128-byte piece, and after the transpose a column's rows from one source rank are one run of jmax numbers
 template<class TF> __device__ __forceinline__ size_t lds_xbuf_index(const LdsSlab& sl, int k, int kx, int row, int nrows)
 {
     const int c = k / sl.ks, kk = k - c*sl.ks, q = kx / sl.nxb, kxl = kx - q*sl.nxb;
-    return ((((size_t)c*sl.npy + q)*sl.ks + kk)*nrows + row)*sl.nxb + kxl;
+    return ((((size_t)c*sl.npy + q)*sl.ks + kk)*sl.nxb + kxl)*nrows + row;
 }
 
 // ======================================================================================================================
@@ -306,10 +308,10 @@ __global__ void __launch_bounds__(BT, (BT >= 128 ? 4 : 1)) pres_in_fftx_kernel(c
         }
         else
         {
-            // modes fastest: thread kx <= nh of every row; kx = 0 and kx = nh (Nyquist) are real
+            // rows fastest, modes kx = 0 .. nh; kx = 0 and kx = nh (Nyquist) are real
             for (int e=(int)tl; e<8*(nh + 1); e+=itot)
             {
-                const int r = e / (nh + 1), kx = e - r*(nh + 1);
+                const int kx = e >> 3, r = e & 7;
                 const int ka = kx & (nh-1);
                 const C2<TF> za = D[r*rp + lds_slot<TF>(ka)], zb = D[r*rp + lds_slot<TF>((nh - ka) & (nh-1))];
                 const C2<TF> ev{TF(0.5)*(za.x + zb.x), TF(0.5)*(za.y - zb.y)};
@@ -628,7 +630,7 @@ __global__ void __launch_bounds__(BT, (BT >= 128 ? 4 : 1)) pres_ifftx_out_kernel
             TF* Dw = reinterpret_cast<TF*>(D);
             for (int e=(int)tl; e<9*(nh + 1); e+=itot)
             {
-                const int r = e / (nh + 1), kx = e - r*(nh + 1);
+                const int kx = e / 9, r = e - 9*kx;
                 const int j = j0 + r - 1;
                 if (r == 0 && !has_south) continue;                      // (that row of LDS stays undefined; its p is never used)
                 const C2<TF> x = a.S[lds_xbuf_index<TF>(a.sl, k, kx, j, a.nrows)];
@@ -725,6 +727,61 @@ __global__ void __launch_bounds__(BT, (BT >= 128 ? 4 : 1)) pres_ifftx_out_kernel
             sched_fence();
         }
         lds_barrier();
+    }
+}
+
+
+// ======================================================================================================================
+// (2s) The transforms along y of the slab form: block = one local mode kxl and eight levels, thread = one row j / mode ky.
+// FWD: the receive buffer of the x -> y transpose ([slice][source rank][k][kxl][jl]: a column's rows from one rank are one run of
+// jmax numbers) -> LDS -> transform -> specy[k][kxl][ky] (unit stride in ky for the Thomas sweeps of k_slab.hip).
+// !FWD: specy -> LDS -> inverse transform -> the send buffer of the y -> x transpose, same layout.
+// One read and one write of the rank's spectral slab per direction; the staged y stage (reorder through LDS tiles + rocFFT in place)
+// makes two of each.
+// ======================================================================================================================
+template<class TF>
+struct SlabYfft
+{
+    C2<TF>* xbuf; C2<TF>* specy; const C2<TF>* Ty;
+    int jtot, jmax, ny, nxb, kbeg, kend;
+    LdsSlab sl;
+};
+template<class TF, int BT, int NY, bool FWD>
+__global__ void __launch_bounds__(BT) slab_yfft_kernel(const SlabYfft<TF> a)
+{
+    HIP_DYNAMIC_SHARED(LdsUnit, lds_raw);
+    const int N = a.jtot, rp = N;
+    C2<TF>* D = reinterpret_cast<C2<TF>*>(lds_raw);
+    C2<TF>* T = D + 8*rp;
+    const int ky = threadIdx.x, kxl = blockIdx.x;            // blockDim.x == jtot
+    T[ky] = a.Ty[ky];
+    const int team = N >> 3, slot = ky / team, l = ky - slot*team;
+    const int k0 = a.kbeg + 8*(int)blockIdx.y;
+    const int r = ky / a.jmax, jl = ky - r*a.jmax;           // source / destination rank and row of this thread's y
+    const int kx = r*a.sl.nxb + kxl;                         // (lds_xbuf_index takes the global mode: q = kx / nxb = r)
+    C2<TF> q[8];
+#pragma unroll
+    for (int m=0; m<8; ++m)
+    {
+        const int k = k0 + m;
+        q[m] = C2<TF>{TF(0), TF(0)};
+        if (k < a.kend) q[m] = FWD ? a.xbuf[lds_xbuf_index<TF>(a.sl, k, kx, jl, a.jmax)] : a.specy[((size_t)k*a.nxb + kxl)*N + ky];
+    }
+#pragma unroll
+    for (int m=0; m<8; ++m) D[m*rp + lds_slot<TF>(ky)] = q[m];
+    lds_barrier();
+    { const C2<TF> none[fft_np(NY)][7] = {}; fft_batch_ct<(FWD ? -1 : +1), (BT <= 512), NY, false>(D + slot*rp, T, 0, l, a.ny, true, none); }
+    if (BT <= 512) lds_barrier();
+#pragma unroll
+    for (int m=0; m<8; ++m)
+    {
+        const int k = k0 + m;
+        if (k < a.kend)
+        {
+            const C2<TF> v = D[m*rp + lds_slot<TF>(ky)];
+            if (FWD) a.specy[((size_t)k*a.nxb + kxl)*N + ky] = v;
+            else     a.xbuf[lds_xbuf_index<TF>(a.sl, k, kx, jl, a.jmax)] = v;
+        }
     }
 }
 

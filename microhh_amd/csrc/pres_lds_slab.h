@@ -7,6 +7,8 @@ namespace mhh
 {
 int lds_slab_usable(const mhh_grid* g);
 int lds_slab_twiddles(const mhh_grid* g, void** tx);
+int lds_slab_twiddles_y(const mhh_grid* g, void** ty);
+int lds_slab_yfft(const mhh_grid* g, bool fwd, void* xbuf, void* specy, const void* ty, int nxb, int npy, int ks, int kbeg, int kend, hipStream_t st);
 int lds_slab_stage_in(const mhh_grid* g, const mhh_fields* f, double dt, void* xbuf, const void* tx, int nxb, int npy, int ks, int kbeg, int kend, hipStream_t st);
 int lds_slab_stage_out(const mhh_grid* g, const mhh_fields* f, const void* xbuf, const void* tx, int nxb, int npy, int ks, int kbeg, int kend, hipStream_t st);
 }

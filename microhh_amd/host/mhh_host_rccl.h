@@ -205,7 +205,13 @@ class Pres_slab
                 if (lds) mhh_check(mhh_pres_slab_lds_fwd(plan, &g, &f, dt, xsend, 0, st));
                 else     mhh_check(mhh_pres_fwd_x_pack(plan, &g, packed, xsend, st));
                 transpose.exec(xsend, xrecv, nbytes / master.npy);            // Transpose::exec_xy
-                mhh_check(mhh_pres_fwd_y_solve_bwd_y(plan, &g, xrecv, xsend, st));
+                if (lds)
+                {
+                    mhh_check(mhh_pres_slab_lds_fwd_y(plan, &g, xrecv, 0, st));
+                    mhh_check(mhh_pres_solve_y(plan, &g, st));
+                    mhh_check(mhh_pres_slab_lds_bwd_y(plan, &g, xsend, 0, st));
+                }
+                else mhh_check(mhh_pres_fwd_y_solve_bwd_y(plan, &g, xrecv, xsend, st));
                 transpose.exec(xsend, xrecv, nbytes / master.npy);            // Transpose::exec_yx
                 if (lds) mhh_check(mhh_pres_slab_lds_bwd(plan, &g, xrecv, &f, 0, st));
                 else     mhh_check(mhh_pres_bwd_x_unpack_output(plan, &g, xrecv, &f, st));
@@ -230,12 +236,14 @@ class Pres_slab
                 for (int c = 0; c < n; ++c)
                 {
                     hip_check(hipStreamWaitEvent(master.stream, events[n + c], 0), "hipStreamWaitEvent");
-                    mhh_check(mhh_pres_fwd_y_chunk(plan, &g, xrecv, c, st));
+                    if (lds) mhh_check(mhh_pres_slab_lds_fwd_y(plan, &g, xrecv, c, st));
+                    else     mhh_check(mhh_pres_fwd_y_chunk(plan, &g, xrecv, c, st));
                 }
                 mhh_check(mhh_pres_solve_y(plan, &g, st));
                 for (int c = 0; c < n; ++c)
                 {
-                    mhh_check(mhh_pres_bwd_y_chunk(plan, &g, xsend, c, st));
+                    if (lds) mhh_check(mhh_pres_slab_lds_bwd_y(plan, &g, xsend, c, st));
+                    else     mhh_check(mhh_pres_bwd_y_chunk(plan, &g, xsend, c, st));
                     exchange(c, events[2*n + c], events[3*n + c]);
                 }
                 for (int c = 0; c < n; ++c)

@@ -417,7 +417,12 @@ class HotPath:
         else:
             self._ok(lib.mhh_pres_fwd_x_pack(self.plan, self.G, packed, self.xsend.data_ptr(), st))
         self._transpose()                                                    # Transpose::exec_xy
-        self._ok(lib.mhh_pres_fwd_y_solve_bwd_y(self.plan, self.G, self.xrecv.data_ptr(), self.xsend.data_ptr(), self.stream))
+        if lds_x:       # the y transforms read / write the transposes' buffers directly, around the Thomas sweeps
+            self._ok(lib.mhh_pres_slab_lds_fwd_y(self.plan, self.G, self.xrecv.data_ptr(), 0, self.stream))
+            self._ok(lib.mhh_pres_solve_y(self.plan, self.G, self.stream))
+            self._ok(lib.mhh_pres_slab_lds_bwd_y(self.plan, self.G, self.xsend.data_ptr(), 0, self.stream))
+        else:
+            self._ok(lib.mhh_pres_fwd_y_solve_bwd_y(self.plan, self.G, self.xrecv.data_ptr(), self.xsend.data_ptr(), self.stream))
         self._transpose()                                                    # Transpose::exec_yx
         if lds_x:
             self._ok(lib.mhh_pres_slab_lds_bwd(self.plan, self.G, self.xrecv.data_ptr(), F, 0, self.stream))
@@ -480,10 +485,12 @@ class HotPath:
         for c in range(n):
             if two_streams:
                 main.wait_event(self._sl_ev[1][c])
-            self._ok(lib.mhh_pres_fwd_y_chunk(self.plan, self.G, self.xrecv.data_ptr(), c, self.stream))
+            if lds_x: self._ok(lib.mhh_pres_slab_lds_fwd_y(self.plan, self.G, self.xrecv.data_ptr(), c, self.stream))
+            else:     self._ok(lib.mhh_pres_fwd_y_chunk(self.plan, self.G, self.xrecv.data_ptr(), c, self.stream))
         self._ok(lib.mhh_pres_solve_y(self.plan, self.G, self.stream))
         for c in range(n):
-            self._ok(lib.mhh_pres_bwd_y_chunk(self.plan, self.G, self.xsend.data_ptr(), c, self.stream))
+            if lds_x: self._ok(lib.mhh_pres_slab_lds_bwd_y(self.plan, self.G, self.xsend.data_ptr(), c, self.stream))
+            else:     self._ok(lib.mhh_pres_bwd_y_chunk(self.plan, self.G, self.xsend.data_ptr(), c, self.stream))
             exchange(c, *( (self._sl_ev[2][c], self._sl_ev[3][c]) if two_streams else (None, None) ))
         for c in range(n):
             if two_streams:

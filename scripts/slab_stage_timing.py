@@ -43,6 +43,7 @@ res = {
  "pres_output south row": timeit(lambda: lib.mhh_pres_output_south_row(hp.G, f, st)),
  "LDS x stage 1: input + x transform -> send buffer": timeit(lambda: lib.mhh_pres_slab_lds_fwd(hp.plan, hp.G, f, 1.0, hp.xsend.data_ptr(), 0, st)) if lib.mhh_pres_slab_has_lds(hp.plan) and hp.pres_chunks == 1 else float("nan"),
  "LDS x stage 3: receive buffer -> x transform + p + output": timeit(lambda: lib.mhh_pres_slab_lds_bwd(hp.plan, hp.G, hp.xrecv.data_ptr(), f, 0, st)) if lib.mhh_pres_slab_has_lds(hp.plan) and hp.pres_chunks == 1 else float("nan"),
+ "LDS y stage: y transform in | Thomas | y transform out": timeit(lambda: (lib.mhh_pres_slab_lds_fwd_y(hp.plan, hp.G, hp.xrecv.data_ptr(), 0, st), lib.mhh_pres_solve_y(hp.plan, hp.G, st), lib.mhh_pres_slab_lds_bwd_y(hp.plan, hp.G, hp.xsend.data_ptr(), 0, st))) if lib.mhh_pres_slab_has_lds(hp.plan) and hp.pres_chunks == 1 else float("nan"),
  "(two-kernel form) bwd_x_unpack": timeit(lambda: lib.mhh_pres_bwd_x_unpack(hp.plan, hp.G, hp.xrecv.data_ptr(), f, st)),
  "(two-kernel form) pres_output": timeit(lambda: lib.mhh_pres_output_order(hp.G, 2, f, st)),
  "full step (no comm)": timeit(hp.step),
