@@ -330,7 +330,10 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32" if rhs_only else "f64", "data": "synthetic",
         "config": {"workload": desc, "grid": [itot, jtot, ktot], "decomposition": "slab-y npx=1 npy=%d" % world,
-                   "ghost_cells": [hp.grid.igc, hp.grid.jgc, hp.grid.kgc], "rhs": "unfused" if args.unfused else "fused", "halo_overlap": bool(overlapped), "launch": "hipGraph replay" if use_graph else "call by call"},
+                   "ghost_cells": [hp.grid.igc, hp.grid.jgc, hp.grid.kgc], "rhs": "unfused" if args.unfused else "fused",
+                   **({"pres_k_slices": hp.pres_chunks, "pres_form": "x and y transforms in LDS on the transposes' buffers" if (hp.slim and hp.lib.mhh_pres_slab_has_lds(hp.plan) == 1) else "staged (rocFFT)",
+                       "note": "halo overlap and k-sliced transposes are the defaults for N > 1 without a multi-GPU measurement behind them (no node was available to the builder); "
+                               "MHH_OVERLAP=0 / MHH_PRES_CHUNKS=1 switch them off"} if hp.slab else {}), "halo_overlap": bool(overlapped), "launch": "hipGraph replay" if use_graph else "call by call"},
         "roofline": {"bound": "hbm", "kernel": "fused RHS (advec+diff) pass" if not args.unfused else "advec+diff launches",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None, "alg_bytes_per_cell": hp.alg_bytes_rhs(), "ms_per_launch": rhs_ms},

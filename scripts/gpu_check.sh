@@ -12,7 +12,7 @@ if [ $rc -gt 1 ]; then echo "pytest crashed (rc=$rc): stopping"; exit $rc; fi
 echo "== smoke"; timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1 || { tail -20 $OUT/smoke.log; echo "smoke failed"; }
 tail -2 $OUT/smoke.log
 for wl in taylorgreen64 drycblles256 drycblles512 moser600 gabls1_1024; do
-  echo "== bench $wl"; timeout -k 10 600 python bench.py --workload $wl --steps 10 --warmup 3 > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err || { tail -5 $OUT/bench_$wl.err; exit 3; }
+  echo "== bench $wl"; timeout -k 10 600 python bench.py --workload $wl --steps 20 --warmup 3 > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err || { tail -5 $OUT/bench_$wl.err; exit 3; }
   cat $OUT/bench_$wl.json
 done
 echo "== bench drycblles512 unfused"; timeout -k 10 600 python bench.py --workload drycblles512 --steps 10 --warmup 3 --unfused --no-cpu-baseline > $OUT/bench_drycblles512_unfused.json 2> $OUT/bench_unfused.err || exit 4
