@@ -150,34 +150,67 @@ def recorded_traffic(workload, igc=None):
             os.path.relpath(best[0], ROOT) + " (recorded by rocprofv3 PMC passes on these sources, not measured in this run)")
 
 
-def sample_clock_and_power(fn, sync, seconds=1.6):
-    """Engine clock and socket power while `fn` (one kernel launch) loops for `seconds`: two rocm-smi samples from this process while
-    the GPU works. The fused RHS kernel runs at the board's power cap with the engine clock throttled below its 2.4 GHz maximum --
-    the limit its roofs have to be read against (profiles/r3_march_kernel.md). None where rocm-smi is not available."""
-    import re
+SAMPLER = r"""
+import json, re, subprocess, sys, time
+for line in sys.stdin:
+    if line.strip() != "go":
+        continue
+    got = []
+    for n in range(2):
+        try:
+            out = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showmaxpower"], capture_output=True, text=True, timeout=20).stdout
+        except Exception:
+            break
+        sclk = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", out)
+        pw = re.search(r"Current Socket Graphics Package Power \(W\): ([0-9.]+)", out)
+        cap = re.search(r"Max Graphics Package Power \(W\): ([0-9.]+)", out)
+        if sclk and pw:
+            got.append((int(sclk.group(1)), float(pw.group(1)), float(cap.group(1)) if cap else None))
+        time.sleep(0.2)
+    print(json.dumps(got), flush=True)
+"""
+
+
+def start_power_sampler():
+    """A helper process that samples rocm-smi on request, started BEFORE this process touches the GPU (a process that has initialised
+    the GPU must not exec another program on this pool; the helper never touches the GPU). None under a profiler (its preloaded library
+    initialises the GPU before main() runs) or where rocm-smi is missing."""
     import shutil
     import subprocess
-    if not shutil.which("rocm-smi"):
+    if not shutil.which("rocm-smi") or "rocprof" in os.environ.get("LD_PRELOAD", "") or os.environ.get("ROCPROFILER_REGISTER_FORCE_LOAD") or os.environ.get("ROCP_TOOL_LIBRARIES"):
         return None
-    t0 = time.time(); got = []
-    while time.time() - t0 < seconds:
+    try:
+        return subprocess.Popen([sys.executable, "-c", SAMPLER], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+    except OSError:
+        return None
+
+
+def sample_clock_and_power(sampler, fn, sync, seconds=2.0):
+    """Engine clock and socket power while `fn` (one kernel launch) loops: the helper takes two rocm-smi samples while the GPU works
+    through a queue of launches. The fused RHS kernel runs at the board's power cap with the engine clock throttled below its 2.4 GHz
+    maximum -- the limit its roofs have to be read against (profiles/r3_march_kernel.md)."""
+    if sampler is None:
+        return None
+    for _ in range(30):
+        fn()
+    sync()
+    t0 = time.time()
+    try:
+        sampler.stdin.write("go\n"); sampler.stdin.flush()
+    except OSError:
+        return None
+    while time.time() - t0 < seconds:                      # keep the queue full while the helper samples
         for _ in range(40):
             fn()
-        if time.time() - t0 > 0.5 and len(got) < 2:          # the queue is now ~40 launches deep: the sample falls inside the work
-            try:
-                out = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showmaxpower"], capture_output=True, text=True, timeout=20).stdout
-            except (OSError, subprocess.SubprocessError):
-                return None
-            sclk = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", out)
-            pw = re.search(r"Current Socket Graphics Package Power \(W\): ([0-9.]+)", out)
-            cap = re.search(r"Max Graphics Package Power \(W\): ([0-9.]+)", out)
-            if sclk and pw:
-                got.append((int(sclk.group(1)), float(pw.group(1)), float(cap.group(1)) if cap else None))
         sync()
+    try:
+        got = json.loads(sampler.stdout.readline() or "[]")
+    except ValueError:
+        got = []
     if not got:
         return None
-    return {"sclk_mhz": max(g[0] for g in got), "socket_w": max(g[1] for g in got), "cap_w": got[0][2], "samples": len(got),
-            "how": "rocm-smi sampled from this process while the fused RHS launch loops (outside the timed region)"}
+    return {"sclk_mhz": min(g[0] for g in got), "socket_w": max(g[1] for g in got), "cap_w": got[0][2], "samples": len(got),
+            "how": "rocm-smi sampled by a helper process while the fused RHS launch loops (outside the timed region)"}
 
 
 def main():
@@ -209,6 +242,8 @@ def main():
 
     if args.build == "fma":
         os.environ["MHH_LIB"] = os.path.join(ROOT, "microhh_amd", "libmhh_hip_fma.so")
+    # (before anything touches the GPU)
+    sampler = start_power_sampler() if (args.device == "cuda" and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_power_sample and not args.unfused) else None
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -357,7 +392,7 @@ def main():
     # maximum engine clock and at the clock it actually holds under this kernel (sampled live below: the board runs it at its power cap).
     power = None
     if world == 1 and on_gpu and not args.unfused and not args.no_power_sample:
-        power = sample_clock_and_power(rhs, lambda: torch.cuda.synchronize())
+        power = sample_clock_and_power(sampler, rhs, lambda: torch.cuda.synchronize())
         if power:
             out["power"] = power
     if valu_insts:
@@ -399,6 +434,11 @@ def main():
         out["data"] = "synthetic; REHEARSAL of the N > 1 path with all ranks on one GPU (gloo, host-staged messages): not a measurement"
     if rank == 0 and world == 1 and not args.no_cpu_baseline and on_gpu:
         out["cpu_baseline"] = cpu_baseline("drycblles" if case == "gabls1" else case, sample=(min(itot, 256), min(jtot, 256), min(ktot, 256)), with_pres=not rhs_only)
+    if sampler is not None:
+        try:
+            sampler.stdin.close(); sampler.wait(timeout=10)
+        except Exception:
+            pass
     hp.close()
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -22,8 +22,8 @@ for wl in slab8of512 gabls1_slab8; do
   cat $OUT/bench_$wl.json
 done
 echo "== rocprofv3 kernel stats (moser600)"
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_moser -- python3 bench.py --workload moser600 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/prof_moser_bench.json 2> $OUT/prof_moser.err || { tail -5 $OUT/prof_moser.err; exit 5; }
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_moser -- python3 bench.py --workload moser600 --steps 5 --warmup 2 --no-cpu-baseline --no-power-sample > $OUT/prof_moser_bench.json 2> $OUT/prof_moser.err || { tail -5 $OUT/prof_moser.err; exit 5; }
 echo "== rocprofv3 kernel stats (drycblles512)"
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --workload drycblles512 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/prof_bench.json 2> $OUT/prof.err || { tail -5 $OUT/prof.err; exit 5; }
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --workload drycblles512 --steps 5 --warmup 2 --no-cpu-baseline --no-power-sample > $OUT/prof_bench.json 2> $OUT/prof.err || { tail -5 $OUT/prof.err; exit 5; }
 find $OUT/prof -name "*kernel_stats*.csv" | head -3
 f=$(find $OUT/prof -name "*kernel_stats*.csv" | head -1); [ -n "$f" ] && head -25 "$f"

@@ -8,7 +8,7 @@ TAG=${1:-r3z}
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 bash scripts/gpu_check.sh $TAG > $OUT/check.log 2>&1; echo "gpu_check rc=$?"; grep -E "passed|failed|smoke ok" $OUT/check.log | head -5
 echo "== default invocation under rocprofv3"
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_default -- python3 bench.py > $OUT/bench_default_invocation.json 2> $OUT/bench_default_invocation.err || tail -3 $OUT/bench_default_invocation.err
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_default -- python3 bench.py --no-power-sample > $OUT/bench_default_invocation.json 2> $OUT/bench_default_invocation.err || tail -3 $OUT/bench_default_invocation.err
 timeout -k 10 600 python bench.py > $OUT/bench_default_plain.json 2> $OUT/bench_default_plain.err || tail -3 $OUT/bench_default_plain.err
 echo "== igc = 16"
 timeout -k 10 300 python bench.py --igc 16 --no-cpu-baseline > $OUT/bench_drycblles512_igc16.json 2> $OUT/bench_igc16.err || tail -3 $OUT/bench_igc16.err

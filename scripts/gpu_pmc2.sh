@@ -17,7 +17,7 @@ for name in $LIBS; do
   while read -r grp; do
     [ -z "$grp" ] && continue; case "$grp" in \#*) continue;; esac
     i=$((i+1))
-    timeout -k 10 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/$name/g$i -- python3 bench.py --workload $WL --steps 4 --warmup 1 --no-cpu-baseline --no-fma-line $BENCH_ARGS > $OUT/$name.g$i.json 2> $OUT/$name.g$i.err || { echo "$name group $i ($grp) failed"; tail -2 $OUT/$name.g$i.err; }
+    timeout -k 10 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/$name/g$i -- python3 bench.py --workload $WL --steps 4 --warmup 1 --no-cpu-baseline --no-fma-line --no-power-sample $BENCH_ARGS > $OUT/$name.g$i.json 2> $OUT/$name.g$i.err || { echo "$name group $i ($grp) failed"; tail -2 $OUT/$name.g$i.err; }
   done < $GROUPS_FILE
   python3 - $OUT/$name "$PAT" "$name" <<'PY'
 import csv, glob, sys, collections

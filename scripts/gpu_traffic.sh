@@ -12,7 +12,7 @@ for v in "" $VARIANTS; do
   name=$(basename "${v:-default}" .so)
   export MHH_LIB=${v:+$PWD/$v}
   for c in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
-    timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$name/$c -- python3 bench.py --workload $WL --steps 10 --warmup 2 --no-cpu-baseline --no-fma-line $BENCH_ARGS > $OUT/$name.$c.json 2> $OUT/$name.$c.err || { echo "$name $c failed"; tail -2 $OUT/$name.$c.err; }
+    timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$name/$c -- python3 bench.py --workload $WL --steps 10 --warmup 2 --no-cpu-baseline --no-fma-line --no-power-sample $BENCH_ARGS > $OUT/$name.$c.json 2> $OUT/$name.$c.err || { echo "$name $c failed"; tail -2 $OUT/$name.$c.err; }
   done
   python3 - $OUT/$name "$PAT" "$name" "$WL" "$BENCH_ARGS" <<'PY'
 import csv, glob, sys
