@@ -232,6 +232,9 @@ int mhh_diff_exec_viscosity_rows2(const mhh_grid* g, int scheme, const mhh_field
  * take the one-thread-per-cell kernel, same bits) */
 unsigned long long mhh_stat_visc_march_launches(void);
 unsigned long long mhh_stat_rhs44_march_launches(void);   /* same for the k-marching form of (advec_4, diff_4) in mhh_rhs_exec */
+/* self test of a device primitive of exec_viscosity: the square root for arguments known to be >= 2^-767 (csrc/gfx950_prims.h,
+ * sqrt_in_range) against the compiler's sqrt on n arguments drawn from `seed`; *mismatches (host memory) must come back 0 */
+int mhh_selftest_sqrt_in_range(unsigned long long n, unsigned long long seed, unsigned long long* mismatches, void* stream);
 int mhh_diff_exec(const mhh_grid* g, int scheme, const mhh_fields* f, const mhh_diff_params* p, void* stream);
 
 /* Thermo_dry::exec buoyancy tendency, calc_buoyancy_tend_2nd / _4th (src/thermo_dry.cxx:165-197,

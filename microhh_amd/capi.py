@@ -54,6 +54,7 @@ SIGNATURES = {
     "mhh_advec_s_lim": (ci, [GP, vp, vp, vp, vp, vp, vp, vp, vp]),
     "mhh_advec_exec": (ci, [GP, ci, FP, vp]),
     "mhh_stat_visc_march_launches": (C.c_ulonglong, []),
+    "mhh_selftest_sqrt_in_range": (ci, [C.c_ulonglong, C.c_ulonglong, C.POINTER(C.c_ulonglong), vp]),
     "mhh_diff_exec_viscosity_rows": (ci, [GP, ci, FP, DP, ci, ci, vp]),
     "mhh_diff_exec_viscosity_rows2": (ci, [GP, ci, FP, DP, ci, ci, ci, ci, vp]),
     "mhh_rhs_exec_rows": (ci, [GP, ci, ci, FP, DP, ci, ci, vp]),

@@ -219,6 +219,36 @@ __device__ __forceinline__ void sched_fence() {}
 // the same thing: without it, values loaded in one loop iteration and first used in the next (the prefetched tendencies)
 // get a compiler-inserted vmcnt(0) at that use -- AFTER the next level's copies have been issued, draining them.
 __device__ __forceinline__ void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_waitcnt(0x0F70); }
+// The value lane `lane` (wave-uniform) holds of a per-lane value, as a wave-uniform value: a wave computes up to 64 different uniform
+// values with ONE vector instruction sequence (lane l works value l) and hands them out one per iteration with two v_readlane --
+// e.g. a division by a per-level constant, which has no scalar form. `same` = the value computed the ordinary way: what the CPU
+// emulation of the kernels returns (its lanes are independent threads); unused on the device.
+__device__ __forceinline__ double value_of_lane(double v, int lane, double /*same*/)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, lane), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), lane);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ float value_of_lane(float v, int lane, float /*same*/)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+// Square root of a double known to lie in [2^-767, +inf): the compiler's own expansion of sqrt on this target (v_rsq_f64 seed, two
+// Goldschmidt steps, two residual corrections -- the same ten instructions on the same values, hence the same bits) without the
+// seven instructions around it that serve arguments outside that range: the 2^256 scaling of tiny arguments (compare, select,
+// two ldexp) and the pass-through of 0 and +inf (class test, two selects). An argument of +inf gives NaN here, not +inf.
+__device__ __forceinline__ double sqrt_in_range(double x)
+{
+    const double y  = __builtin_amdgcn_rsq(x);
+    const double g0 = x*y, h0 = y*0.5;
+    const double r0 = __builtin_fma(-h0, g0, 0.5);
+    const double g1 = __builtin_fma(g0, r0, g0), h1 = __builtin_fma(h0, r0, h0);
+    const double d0 = __builtin_fma(-g1, g1, x);
+    const double g2 = __builtin_fma(d0, h1, g1);
+    const double d1 = __builtin_fma(-g2, g2, x);
+    return __builtin_fma(d1, h1, g2);
+}
+__device__ __forceinline__ float sqrt_in_range(float x) { return __builtin_sqrtf(x); }
 // true if the predicate holds on any lane of the wave (wave-uniform)
 __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
 }

@@ -158,6 +158,14 @@ __device__ __forceinline__ TF fft_norm(TF v, int itot, int jtot, TF ri, TF rj) {
 static inline bool is_pow2(int n) { return n > 0 && (n & (n-1)) == 0; }
 
 
+// a divisor div_known (cell_ops.h) may take: positive, normal, significand not all ones (1/3, 2/3, 1, 0.7 ... qualify)
+template<class TF> inline bool known_divisor_ok(TF d)
+{
+    if (!(d > TF(0)) || !std::isfinite(d) || !std::isnormal(d)) return false;
+    int e; const TF m = std::frexp(d, &e);                          // m in [0.5, 1)
+    return std::nextafter(m, TF(1)) != TF(1);
+}
+
 // Low-storage Runge-Kutta coefficients of the time loop (src/timeloop.cxx:250-334): a += cB[substep]*dt*at, then at *= cA[next]
 // (or at = 0 over all cells when the next sub-step is the first of a new step)
 inline bool rk_coefficients(int rkorder, int substep, double& cA, double& cB, bool& reset)

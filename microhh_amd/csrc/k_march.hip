@@ -759,14 +759,6 @@ rhs25_march_kernel(const MarchMetrics<typename lane_of<VT>::scalar> mm, const Gr
 static unsigned long long* g_stamp_buf = nullptr; static size_t g_stamp_n = 0;
 #endif
 
-// 2 tPr must not have an all-ones significand (div_known, cell_ops.h); 1/3, 1, 0.7 ... have not
-template<class TF> bool known_divisor_ok(TF d)
-{
-    if (!(d > TF(0)) || !std::isfinite(d) || !std::isnormal(d)) return false;
-    int e; const TF m = std::frexp(d, &e);                          // m in [0.5, 1)
-    return std::nextafter(m, TF(1)) != TF(1);
-}
-
 // mode 0: advec_2i5 + diff_smag2 (the fused pass); 1: advec_2i5 only (p may be null); 2: diff_smag2 only
 // VT = lane value type: double, float, or F2 = two fp32 cells per lane (packed arithmetic; needs an even imax)
 template<class VT>

@@ -28,7 +28,15 @@ template<class TF> struct ViscFields
     const TF* __restrict__ dudz; const TF* __restrict__ dvdz; const TF* __restrict__ dbdz; const TF* __restrict__ z0m;
     const TF* __restrict__ N2; const TF* __restrict__ th; const TF* __restrict__ thref; const TF* __restrict__ mlen0; const TF* __restrict__ mlen2;
     TF grav, tPr; int sm, neutral, ex;
+    TF rtPr;                       // RN(1 / tPr) from the host, or 0: the division by tPr as it stands (div_known, cell_ops.h)
 };
+
+// acc + 0.125*q and 2*acc + c as ONE fma each: the products with powers of two are exact (q, acc far from the subnormal range or exactly
+// zero), so the fma rounds where the reference's addition rounds -- the same bits, a vector instruction less per term. MHH_VISC_EXACT_FMA=0: as written.
+#ifndef MHH_VISC_EXACT_FMA
+#define MHH_VISC_EXACT_FMA 1
+#endif
+template<class TF> __device__ __forceinline__ TF add_eighth(TF acc, TF q) { return MHH_VISC_EXACT_FMA ? tfma(TF(0.125), q, acc) : acc + TF(0.125)*q; }
 
 #ifndef MHH_VISC_OCC
 #define MHH_VISC_OCC 4
@@ -86,7 +94,19 @@ __global__ void __launch_bounds__(64*NJ, MHH_VISC_OCC) visc_march_kernel(const G
     wait_vmem();
     __syncthreads();
 
-    TF bu0 = 0, bu1 = 0, bv0 = 0, bv1 = 0;                            // carried bottom-face terms (already x 0.125)
+    // grav / thref[k] is a per-level constant, but an fp64 division has no scalar form: lane l of every wave divides for level kb + l
+    // ONCE per chunk (chunks are at most 64 levels), and a level takes its quotient from that lane -- the same correctly rounded
+    // quotient, ~12 vector instructions per level less
+#ifndef MHH_VISC_SQRT_RANGE
+#define MHH_VISC_SQRT_RANGE 1
+#endif
+#ifndef MHH_VISC_LANE_QUOT
+#define MHH_VISC_LANE_QUOT 1
+#endif
+    const bool lane_quot = MHH_VISC_LANE_QUOT && !f.neutral && !EXT_N2 && f.thref && (ke - kb) <= 64;
+    TF gq = TF(0);
+    if (lane_quot) { const int kq = kb + tx; gq = f.grav / f.thref[kq < g.kcells ? kq : g.kcells-1] * TF(0.5); }   // grav/thref[k] * 0.5: the first product of N2 below
+    TF bu0 = 0, bu1 = 0, bv0 = 0, bv1 = 0;                            // carried bottom-face terms: the squares (their 1/8 is applied where they are added)
     // The result of level k is stored at the top of iteration k+1, after the next copy has been issued: s_waitcnt vmcnt(0)
     // before the barrier also waits for stores (gfx9 has one counter), and a store issued right before it would expose its
     // full latency on every level.
@@ -106,10 +126,10 @@ __global__ void __launch_bounds__(64*NJ, MHH_VISC_OCC) visc_march_kernel(const G
         const TF dzhip = uniform_load(g.dzhi, k+1);
 
         // top-face shear terms of level k == bottom-face terms of level k+1 (src/diff_smag2.cxx:140-141,146-147 vs :138-139,144-145)
-        const TF tu0 = TF(0.125)*sq((ukp[0 ]-uk[0 ])*dzhip + (wkp[0 ]-wkp[-1 ])*dxi);
-        const TF tu1 = TF(0.125)*sq((ukp[1 ]-uk[1 ])*dzhip + (wkp[1 ]-wkp[0  ])*dxi);
-        const TF tv0 = TF(0.125)*sq((vkp[0 ]-vk[0 ])*dzhip + (wkp[0 ]-wkp[-TI])*dyi);
-        const TF tv1 = TF(0.125)*sq((vkp[TI]-vk[TI])*dzhip + (wkp[TI]-wkp[0  ])*dyi);
+        const TF tu0 = sq((ukp[0 ]-uk[0 ])*dzhip + (wkp[0 ]-wkp[-1 ])*dxi);
+        const TF tu1 = sq((ukp[1 ]-uk[1 ])*dzhip + (wkp[1 ]-wkp[0  ])*dxi);
+        const TF tv0 = sq((vkp[0 ]-vk[0 ])*dzhip + (wkp[0 ]-wkp[-TI])*dyi);
+        const TF tv1 = sq((vkp[TI]-vk[TI])*dzhip + (wkp[TI]-wkp[0  ])*dyi);
 
         if (k >= kb && active)
         {
@@ -117,10 +137,10 @@ __global__ void __launch_bounds__(64*NJ, MHH_VISC_OCC) visc_march_kernel(const G
             TF acc = sq((uk[1]-uk[0])*dxi);
             acc = acc + sq((vk[TI]-vk[0])*dyi);
             acc = acc + sq((wkp[0]-wk[0])*uniform_load(g.dzi, k));
-            acc = acc + TF(0.125)*sq((uk[0    ]-uk[-TI  ])*dyi + (vk[0   ]-vk[-1   ])*dxi);
-            acc = acc + TF(0.125)*sq((uk[1    ]-uk[1-TI ])*dyi + (vk[1   ]-vk[0    ])*dxi);
-            acc = acc + TF(0.125)*sq((uk[TI   ]-uk[0    ])*dyi + (vk[TI  ]-vk[TI-1 ])*dxi);
-            acc = acc + TF(0.125)*sq((uk[1+TI ]-uk[1    ])*dyi + (vk[1+TI]-vk[TI   ])*dxi);
+            acc = add_eighth(acc, sq((uk[0    ]-uk[-TI  ])*dyi + (vk[0   ]-vk[-1   ])*dxi));
+            acc = add_eighth(acc, sq((uk[1    ]-uk[1-TI ])*dyi + (vk[1   ]-vk[0    ])*dxi));
+            acc = add_eighth(acc, sq((uk[TI   ]-uk[0    ])*dyi + (vk[TI  ]-vk[TI-1 ])*dxi));
+            acc = add_eighth(acc, sq((uk[1+TI ]-uk[1    ])*dyi + (vk[1+TI]-vk[TI   ])*dxi));
             if (mo)
             {   // unresolved wall: MOST gradients replace the resolved du/dz, dv/dz (src/diff_smag2.cxx:72-114)
                 acc = acc + TF(0.5)*sq(dudz_c);
@@ -136,23 +156,38 @@ __global__ void __launch_bounds__(64*NJ, MHH_VISC_OCC) visc_march_kernel(const G
             }
             else
             {
-                acc = acc + bu0; acc = acc + bu1; acc = acc + tu0; acc = acc + tu1;
-                acc = acc + bv0; acc = acc + bv1; acc = acc + tv0; acc = acc + tv1;
+                acc = add_eighth(acc, bu0); acc = add_eighth(acc, bu1); acc = add_eighth(acc, tu0); acc = add_eighth(acc, tu1);
+                acc = add_eighth(acc, bv0); acc = add_eighth(acc, bv1); acc = add_eighth(acc, tv0); acc = add_eighth(acc, tv1);
             }
-            TF s2 = TF(2.)*acc;
-            s2 += 1.e-9;
+            TF s2;
+            if (MHH_VISC_EXACT_FMA) s2 = tfma(TF(2.), acc, TF(1.e-9));      // 2*acc is exact: one rounding, where `s2 += 1e-9` rounds
+            else { s2 = TF(2.)*acc; s2 += 1.e-9; }
             const int c = col + k*kk;
             TF n2 = TF(0);
             if (!f.neutral)
             {
                 if (mo) n2 = dbdz_c;
                 else if (EXT_N2) n2 = f.N2[c];
-                else n2 = f.grav/uniform_load(f.thref, k)*TF(0.5)*(thp - thm)*uniform_load(g.dzi, k);
+                else
+                {
+                    const TF gth = lane_quot ? value_of_lane(gq, k - kb, f.grav/f.thref[k]*TF(0.5)) : f.grav/uniform_load(f.thref, k)*TF(0.5);
+                    n2 = gth*(thp - thm)*uniform_load(g.dzi, k);
+                }
             }
             c_pending = c;
             const TF fac = f.mlen2 ? uniform_load(f.mlen2, k)            // uniform z0m: per-level table, same bits
                                    : evisc_mlen2(f.sm, f.neutral, uniform_load(f.mlen0, k), f.sm ? uniform_load(g.z, k) : TF(0), z0m_c);
-            ev_pending = evisc_from_mlen2(fac, s2, n2, f.neutral, f.tPr);
+            // evisc_from_mlen2 (cell_ops.h) with its two square roots as sqrt_in_range (s2 >= 1e-9, 1 - rit >= 1e-9) and, where tPr
+            // allows, its division by the uniform tPr as div_known (the correctly rounded quotient in five fmas)
+            const TF rs2 = MHH_VISC_SQRT_RANGE ? sqrt_in_range(s2) : dsqrt2(s2);
+            if (f.neutral) ev_pending = fac * rs2;
+            else
+            {
+                TF rit = (f.rtPr != TF(0)) ? div_known(n2 / s2, f.tPr, f.rtPr) : n2 / s2 / f.tPr;
+                rit = tmin(rit, TF(1.-1.e-9));
+                const TF om = TF(1.)-rit;
+                ev_pending = fac * rs2 * (MHH_VISC_SQRT_RANGE ? sqrt_in_range(om) : dsqrt2(om));
+            }
         }
         bu0 = tu0; bu1 = tu1; bv0 = tv0; bv1 = tv1;
         wait_vmem();                  // unconditional: every path back to the loop head carries a vmcnt(0) the compiler can see
@@ -171,6 +206,10 @@ int visc_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p
     vf.dudz = cp<TF>(f->dudz); vf.dvdz = cp<TF>(f->dvdz); vf.dbdz = cp<TF>(f->dbdz); vf.z0m = cp<TF>(f->z0m);
     vf.N2 = cp<TF>(p->N2); vf.th = cp<TF>(th); vf.thref = cp<TF>(p->thref); vf.mlen0 = cp<TF>(p->mlen0); vf.mlen2 = cp<TF>(p->mlen2);
     vf.grav = TF(p->grav); vf.tPr = TF(p->tPr); vf.sm = p->surface_model; vf.neutral = p->neutral; vf.ex = ex;
+#ifndef MHH_VISC_DIVKNOWN
+#define MHH_VISC_DIVKNOWN 1
+#endif
+    vf.rtPr = (MHH_VISC_DIVKNOWN && known_divisor_ok(vf.tPr)) ? TF(1.)/vf.tPr : TF(0);
     int kc = (j0 >= 0 && (j1 - j0 + (j2 >= 0 ? j3 - j2 : 0)) * 4 <= g->jmax) ? 16 : MHH_VISC_KC;      // few rows: short k-chunks fill the GPU
     { const char* e = getenv("MHH_VISC_KC_RT"); if (e && atoi(e) >= 8) kc = atoi(e); }         // tuning runs
     const MarchTiling t = make_march_tiling(g, NJ, kc, j0, j1, 64, j2, j3);
@@ -190,6 +229,44 @@ int visc_launch(const mhh_grid* g, const mhh_fields* f, const mhh_diff_params* p
     return MHH_OK;
 }
 } // namespace
+
+// ---- self test: sqrt_in_range (gfx950_prims.h) against the compiler's sqrt, bit for bit ------------------------------------
+namespace
+{
+__global__ void __launch_bounds__(256) sqrt_selftest_kernel(unsigned long long n, unsigned long long seed, unsigned long long* bad)
+{
+    unsigned long long miss = 0;
+    for (unsigned long long i = blockIdx.x*256ull + threadIdx.x; i < n; i += gridDim.x*256ull)
+    {
+        // splitmix64 of (seed, i): a random significand under an exponent in [2^-767, 2^1023]; every 16th value near the lower
+        // bounds the kernel feeds it (1e-9 and a few ulps above)
+        unsigned long long z = seed + 0x9E3779B97F4A7C15ull*(i+1);
+        z = (z ^ (z >> 30))*0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27))*0x94D049BB133111EBull; z ^= z >> 31;
+        const unsigned long long mant = z & 0xFFFFFFFFFFFFFull;
+        const unsigned long long e = 256ull + (z >> 52) % (2046ull - 256ull + 1ull);        // biased exponent 256 (2^-767) ... 2046
+        double x = __builtin_bit_cast(double, (e << 52) | mant);
+        if ((i & 15u) == 15u) x = __builtin_bit_cast(double, __builtin_bit_cast(unsigned long long, 1.e-9) + (z & 1023u));
+        const double a = sqrt_in_range(x), b = __builtin_sqrt(x);
+        miss += (__builtin_bit_cast(unsigned long long, a) != __builtin_bit_cast(unsigned long long, b));
+    }
+    if (miss) atomicAdd(bad, miss);
+}
+}
+// counts the arguments (n of them, drawn from `seed`) on which sqrt_in_range and sqrt differ: *mismatches must come back 0
+MHH_API int mhh_selftest_sqrt_in_range(unsigned long long n, unsigned long long seed, unsigned long long* mismatches, void* stream)
+{
+    MHH_REQUIRE(mismatches != nullptr, "null result pointer");
+    unsigned long long* d = nullptr;
+    MHH_HIP_TRY(hipMalloc((void**)&d, sizeof(*d)));
+    hipStream_t st = as_stream(stream);
+    hipError_t e = hipMemsetAsync(d, 0, sizeof(*d), st);
+    if (e == hipSuccess) { hipLaunchKernelGGL(sqrt_selftest_kernel, dim3(2048), dim3(256), 0, st, n, seed, d); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(mismatches, d, sizeof(*d), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d);
+    if (e != hipSuccess) { mhh::set_error("sqrt self test failed: %s", hipGetErrorString(e)); return MHH_EHIP; }
+    return MHH_OK;
+}
 
 static unsigned long long g_visc_march_launches = 0;
 // diagnostics: how many times the marching form (as opposed to the one-thread-per-cell form) has been launched

@@ -17,6 +17,10 @@ template<bool RAW = false> inline void lds_dma4(const void* gsrc, void* lds_wave
 inline void wait_vmem() {}
 
 inline bool wave_any(bool) { return true; }
+inline double value_of_lane(double, int, double same) { return same; }
+inline float value_of_lane(float, int, float same) { return same; }
+inline double sqrt_in_range(double x) { return __builtin_sqrt(x); }
+inline float sqrt_in_range(float x) { return __builtin_sqrtf(x); }
 template<class T> inline T stream_load(const T* q) { return *q; }
 template<class T> inline void stream_store(T* q, T v) { *q = v; }
 #define MHH_RAW_DMA 0

@@ -32,6 +32,7 @@ inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { m
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? 0 : 2; }
 inline hipError_t hipFree(void* p) { free(p); return 0; }
+inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 // dynamic LDS: one buffer of a CU's 160 KB (blocks run one at a time)
 extern double g_emul_dyn_lds[160*1024/8];
 #define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(g_emul_dyn_lds);

@@ -870,7 +870,7 @@ def test_exec_viscosity_marching_form_equals_cell_form(be, sm, neutral, dtype):
     for shape in shapes:                      # (17, 9, 8) fp64, (70, ..) / (16, ..) fp32: not 16-byte aligned -> 4-byte copies
         g = cm.grid_2nd(*shape, gc=(3, 3, 1), dtype=dtype)
         c = cm.Case(g, periodic=True)
-        thref = np.full(g.kcells, 300., dtype=dtype)
+        thref = (300. + 7.*np.sin(0.37*np.arange(g.kcells))).astype(dtype)     # a different grav/thref[k] per level (one lane each, k_visc.hip)
         out = {}
         for impl in ("march", "cell"):
             d = B.DevCase(be, c); f = d.fields()
@@ -887,6 +887,18 @@ def test_exec_viscosity_marching_form_equals_cell_form(be, sm, neutral, dtype):
             out[impl] = be.host(d.evisc)
             assert ran == (1 if impl == "march" else 0), (impl, shape, ran)     # 16-byte or 4-byte copies, never the cell form
         assert same(out["march"], out["cell"]), (shape, cm.ulp_diff(out["march"], out["cell"]))
+
+
+@pytest.mark.gpu
+def test_sqrt_in_range_equals_the_compilers_sqrt_on_the_device():
+    """sqrt_in_range (csrc/gfx950_prims.h: the target's sqrt expansion without its range scaling and 0 / inf pass-through) against
+    __builtin_sqrt on 2^28 arguments over [2^-767, 2^1023], one in sixteen within 1024 ulp of the 1e-9 the kernel's arguments
+    are bounded by: not one differing bit."""
+    be = B.get("hip")
+    for seed in (1, 20240607):
+        bad = C.c_ulonglong(12345)
+        B.ok(be, be.lib.mhh_selftest_sqrt_in_range(1 << 28, seed, C.byref(bad), be.stream))
+        assert bad.value == 0, (seed, bad.value)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
