@@ -558,6 +558,24 @@ class HotPath:
         self._ok(self.lib.mhh_pres_check_divergence(self.G, self.cfg["pres"], C.byref(self.fields), self.work.data_ptr(), C.byref(out), self.stream))
         return self._allmax(out.value)
 
+    def projected_divergence(self):
+        """(max |div(u/dt + ut)|, max |div(u/dt)|) over the interior, MAX over ranks: the first is what Pres::exec has just made
+        zero (src/pres_2.cxx:66-94, 156-196), the second the scale to read it against. A self-check of the (distributed) solve for
+        bench.py and the tests, outside any timed region: three temporary fields, their halos, two reductions."""
+        torch = self.torch
+        out = []
+        for with_tend in (True, False):
+            tmp = [(x/self.dt + xt) if with_tend else (x/self.dt) for x, xt in ((self.u, self.ut), (self.v, self.vt), (self.w, self.wt))]
+            self.halo(tmp)
+            f = self._fields()
+            f.u, f.v, f.w = (t.data_ptr() for t in tmp)
+            o = C.c_double(0)
+            self._ok(self.lib.mhh_pres_check_divergence(self.G, self.cfg["pres"], C.byref(f), self.work.data_ptr(), C.byref(o), self.stream))
+            self.sync()
+            out.append(self._allmax(o.value))
+            del tmp
+        return tuple(out)
+
     def cfl(self, dt):
         out = C.c_double(0)
         self._ok(self.lib.mhh_advec_cfl(self.G, self.cfg["advec"], self.u.data_ptr(), self.v.data_ptr(), self.w.data_ptr(), dt, self.work.data_ptr(), C.byref(out), self.stream))
