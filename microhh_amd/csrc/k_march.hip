@@ -242,11 +242,6 @@ rhs25_march_kernel(const MarchMetrics<typename lane_of<VT>::scalar> mm, const Gr
     auto adv = [&](const TF* q, int n) -> const TF* { return reinterpret_cast<const TF*>(reinterpret_cast<const char*>(q) + n*kk8); };
     // the uniform coefficients: read per level from the kernel-argument segment (see MarchMetrics)
     const TF* const kmm = first_kernarg(reinterpret_cast<const TF&>(mm));
-#ifdef MHH_MARCH_F2_PINNED     // experiment: two-cells-per-lane form with the coefficients pinned in scalar registers as in round 2
-    Uniform8<TF> pin0, pin1;
-    pin0.v[0] = sgpr(mm.dxih); pin0.v[1] = sgpr(mm.dyih); pin0.v[2] = sgpr(mm.dxd); pin0.v[3] = sgpr(mm.dyd); pin0.v[4] = sgpr(mm.dxd2); pin0.v[5] = sgpr(mm.dyd2); pin0.v[6] = sgpr(mm.visc); pin0.v[7] = sgpr(mm.quarter);
-    pin1.v[0] = sgpr(mm.dxi); pin1.v[1] = sgpr(mm.dyi); pin1.v[2] = sgpr(mm.dxidxi); pin1.v[3] = sgpr(mm.dyidyi); pin1.v[4] = sgpr(mm.svisc); pin1.v[5] = sgpr(mm.tPr2); pin1.v[6] = sgpr(mm.rtPr2); pin1.v[7] = TF(0);
-#endif
     const TF* __restrict__ tdzi = sgpr(g.dzi); const TF* __restrict__ tdzhi = sgpr(g.dzhi);
 
     // ---- tile movers. A tile is walked in pieces of PW 32-bit words: e = tid + n*NT; piece -> (row, first word) --------
@@ -302,7 +297,6 @@ rhs25_march_kernel(const MarchMetrics<typename lane_of<VT>::scalar> mm, const Gr
     // pl = the plane to copy (a wave-uniform pointer inside the array)
     // a wave takes part in sweep n if its first piece lies inside the tile: a wave-uniform (scalar) condition
     const int wave_p0 = (int)uniform_u32((unsigned)wave_e0);
-    const int wave_ph = (int)uniform_u32((unsigned)ty) & 3;       // this wave's number in the block (a scalar)
     auto dma_tile = [&](const TF* __restrict__ pl, int lo)
     {
 #pragma unroll
@@ -403,11 +397,7 @@ rhs25_march_kernel(const MarchMetrics<typename lane_of<VT>::scalar> mm, const Gr
         // ring slot of plane k+d: inside a rotated group k - kg0 = ROT (mod 6), a constant for the rings whose depth divides 6
         auto sl = [&](int d, int r) { return (ROT >= 0 && 6 % r == 0) ? (ROT + d + 12) % r : slot(k + d, r); };
         const TF* const mq = sgpr(kmm);                          // opaque per level: the loads stay inside the level
-#ifdef MHH_MARCH_F2_PINNED
-        const Uniform8<TF> mg0 = (CW == 2) ? pin0 : uniform_load8(mq);
-#else
         const Uniform8<TF> mg0 = uniform_load8(mq);
-#endif
         const TF dxih = mg0.v[0], dyih = mg0.v[1], dxd = mg0.v[2], dyd = mg0.v[3], dxd2 = mg0.v[4], dyd2 = mg0.v[5], visc = mg0.v[6], quarter = mg0.v[7];
         VT viscv = VT(visc); if constexpr (CW == 1) pin_vgpr(viscv); else pin_vgpr(viscv.v);                    // the viscosity once per level in a vector register (quarter_plus)
         MHH_STAMP(4);                                             // (loop control, window rotation: since the last barrier)
@@ -641,11 +631,7 @@ rhs25_march_kernel(const MarchMetrics<typename lane_of<VT>::scalar> mm, const Gr
                 // every level (the next level carries it), the tendency on updating levels
                 if constexpr (HAS_S)
                 {
-        #ifdef MHH_MARCH_F2_PINNED
-            const Uniform8<TF> mg1 = (CW == 2) ? pin1 : uniform_load8(mq + 8);
-#else
             const Uniform8<TF> mg1 = uniform_load8(mq + 8);
-#endif
                     const TF dxi = mg1.v[0], dyi = mg1.v[1], dxidxi = mg1.v[2], dyidyi = mg1.v[3], svisc = mg1.v[4], tPr2 = mg1.v[5], rtPr2 = mg1.v[6];
                     auto div_tpr = [&](VT x) -> VT { return div_known(x, tPr2, rtPr2); };     // 0.5*x / tPr
                     if (DIF && need_dtop)
@@ -681,23 +667,7 @@ rhs25_march_kernel(const MarchMetrics<typename lane_of<VT>::scalar> mm, const Gr
                 }
             }
         };
-        // MHH_MARCH_ROTSEC: the four waves of a block take the sections in rotated orders (wave w starts with section w). The waves
-        // leave the barrier together and walk the level in lock step: in the same order all four request the same section's LDS reads
-        // at the same time -- 4 x 7 KB through a 128 B/clk pipe -- and every wave waits out the whole burst (~220 cycles per batch,
-        // a third of a level's wave cycles in s_waitcnt lgkmcnt). A tendency is still accumulated in the reference's order: the
-        // rotation only changes WHEN a wave works on which tendency.
-#ifndef MHH_MARCH_ROTSEC
-#define MHH_MARCH_ROTSEC 0
-#endif
-        if constexpr (MHH_MARCH_ROTSEC != 0 && sizeof(TF) == 8)
-        {
-#pragma nounroll
-            for (int n_ = 0; n_ < 4; ++n_) { mfence(); section((n_ + wave_ph) & 3); }
-        }
-        else
-        {
-            mfence(); section(0); mfence(); section(1); mfence(); section(2); mfence(); section(3);
-        }
+        mfence(); section(0); mfence(); section(1); mfence(); section(2); mfence(); section(3);
         if (DSTORE) dsp = upd;
         // ---- carry the top faces down, rotate the windows, advance the plane pointers ------------------------------------
         cTu = Tu; cGu = Gu; cDu = Du; cTv = Tv; cGv = Gv; cDv = Dv; cTw = Tw; cGw = Gw; cDw = Dw; cTs = Ts; cGs = Gs; cDs = Ds;
