@@ -423,10 +423,10 @@ def main():
                             "tolerance": "tendency increments within 64 ulp of the field's largest increment of the bit-exact build (tests/test_fma_build.py)"}
         hp2.close()
     if not rhs_only:
-        # self-check of the solve on the state the timed steps left behind (every rank takes part: halos + MAX over ranks): the
-        # divergence of u/dt + ut, which Pres::exec makes zero, beside the divergence the synthetic u alone carries
+        # self-check of the solve on the state the timed steps left behind (every rank takes part: halos + MAX over ranks):
+        # Pres::input -- the divergence of u/dt + ut, which Pres::exec has just removed -- beside the same of u, v, w alone
         d1, d0 = hp.projected_divergence()
-        out["self_check"] = {"max_abs_div_after_pres": d1, "max_abs_div_of_u_over_dt": d0, "ratio": d1 / d0 if d0 else None}
+        out["self_check"] = {"max_abs_pres_input_after_pres": d1, "max_abs_pres_input_of_u_over_dt": d0, "ratio": d1 / d0 if d0 else None}
     if not on_gpu:
         out["data"] = "synthetic; CPU REHEARSAL of the script (emulated kernels, gloo): not a measurement"
     if hp.comm_timing:

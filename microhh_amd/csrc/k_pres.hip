@@ -58,6 +58,7 @@ struct mhh_pres_plan
 // naturally aligned (16 bytes in fp64): one ds_read_b128 / global_load_dwordx4 per number instead of two 8-byte halves
 template<class TF> struct alignas(2*sizeof(TF)) C2 { TF x, y; };
 #include "pres_lds.h"
+#include "pres_lds4.h"
 
 // ---- host-side coefficient tables (Pres_2::set_values src/pres_2.cxx:125-153; Pres_4::set_values src/pres_4.cxx:179-252)
 template<class TF>
@@ -238,7 +239,7 @@ MHH_API int mhh_pres_plan_create(const mhh_grid* g, int order, const void* host_
     }
     if (!e && order == 4) e = hdma_factor(P);
     if (!e && order == 2) e = tdma_factor(P);
-    if (!e && order == 2) e = pres_lds_setup(P, g);
+    if (!e) e = pres_lds_setup(P, g);
     if (e) { mhh_pres_plan_destroy(P); return e; }
     *out = P;
     return MHH_OK;
@@ -434,29 +435,21 @@ static int tdma_factor(mhh_pres_plan* P)
 // (hdma_factor_kernel, the reference's elimination order) and kept: band n (0..6) at W[(n*(kmax+4) + k)*ncol + col].
 // Every solve is then the two substitution sweeps (hdma_solve_kernel), in place on the spectral array.
 // =======================================================================================================
+// one column: Wc = the column's element of band 0, row 0; row r of band n at Wc[n*bstride + r*ncol]
 template<class TF>
-__global__ void __launch_bounds__(64) hdma_factor_kernel(TF* __restrict__ W,
-                                                  const TF* __restrict__ bmati, const TF* __restrict__ bmatj,
-                                                  const TF* __restrict__ M1, const TF* __restrict__ M2, const TF* __restrict__ M3, const TF* __restrict__ M4,
-                                                  const TF* __restrict__ M5, const TF* __restrict__ M6, const TF* __restrict__ M7,
-                                                  int nxh, int nxp, int jtot, int kmax)
+__device__ __forceinline__ void hdma_factor_column(TF* __restrict__ Wc, size_t ncol, size_t bstride, TF bi, TF bj, bool mean,
+                                                   const TF* __restrict__ M1, const TF* __restrict__ M2, const TF* __restrict__ M3, const TF* __restrict__ M4,
+                                                   const TF* __restrict__ M5, const TF* __restrict__ M6, const TF* __restrict__ M7, int kmax)
 {
-    const int kx = blockIdx.x*64 + threadIdx.x, ky = blockIdx.y;
-    if (kx >= nxh) return;
-    const size_t ncol = (size_t)nxp*jtot, col = kx + (size_t)ky*nxp;
-    const int n = kmax+4;
-    const bool mean = (kx == 0 && ky == 0);
-    TF* __restrict__ m1 = W + 0*(size_t)n*ncol + col; TF* __restrict__ m2 = W + 1*(size_t)n*ncol + col;
-    TF* __restrict__ m3 = W + 2*(size_t)n*ncol + col; TF* __restrict__ m4 = W + 3*(size_t)n*ncol + col;
-    TF* __restrict__ m5 = W + 4*(size_t)n*ncol + col; TF* __restrict__ m6 = W + 5*(size_t)n*ncol + col;
-    TF* __restrict__ m7 = W + 6*(size_t)n*ncol + col;
+    TF* __restrict__ m1 = Wc;             TF* __restrict__ m2 = Wc + bstride;   TF* __restrict__ m3 = Wc + 2*bstride; TF* __restrict__ m4 = Wc + 3*bstride;
+    TF* __restrict__ m5 = Wc + 4*bstride; TF* __restrict__ m6 = Wc + 5*bstride; TF* __restrict__ m7 = Wc + 6*bstride;
 #define A(arr, k) arr[(size_t)(k)*ncol]
     // fill (rows 0,1: bottom bc; 2..kmax+1: interior; kmax+2, kmax+3: top bc)
     A(m1,0)=0; A(m2,0)=0; A(m3,0)=0; A(m4,0)=1; A(m5,0)=0;  A(m6,0)=0; A(m7,0)=-1;
     A(m1,1)=0; A(m2,1)=0; A(m3,1)=0; A(m4,1)=1; A(m5,1)=-1; A(m6,1)=0; A(m7,1)=0;
     for (int k=0; k<kmax; ++k)
     {
-        A(m1,k+2)=M1[k]; A(m2,k+2)=M2[k]; A(m3,k+2)=M3[k]; A(m4,k+2)=M4[k] + bmati[kx] + bmatj[ky];
+        A(m1,k+2)=M1[k]; A(m2,k+2)=M2[k]; A(m3,k+2)=M3[k]; A(m4,k+2)=M4[k] + bi + bj;
         A(m5,k+2)=M5[k]; A(m6,k+2)=M6[k]; A(m7,k+2)=M7[k];
     }
     const int t = kmax+2;
@@ -491,6 +484,35 @@ __global__ void __launch_bounds__(64) hdma_factor_kernel(TF* __restrict__ W,
         if (k == kmax+3) { A(m5,k)=TF(1.); A(m6,k)=TF(1.); A(m7,k)=TF(1.); }
     }
 #undef A
+}
+template<class TF>
+__global__ void __launch_bounds__(64) hdma_factor_kernel(TF* __restrict__ W,
+                                                  const TF* __restrict__ bmati, const TF* __restrict__ bmatj,
+                                                  const TF* __restrict__ M1, const TF* __restrict__ M2, const TF* __restrict__ M3, const TF* __restrict__ M4,
+                                                  const TF* __restrict__ M5, const TF* __restrict__ M6, const TF* __restrict__ M7,
+                                                  int nxh, int nxp, int jtot, int kmax)
+{
+    const int kx = blockIdx.x*64 + threadIdx.x, ky = blockIdx.y;
+    if (kx >= nxh) return;
+    const size_t ncol = (size_t)nxp*jtot, col = kx + (size_t)ky*nxp;
+    hdma_factor_column(W + col, ncol, (size_t)(kmax+4)*ncol, bmati[kx], bmatj[ky], kx == 0 && ky == 0, M1, M2, M3, M4, M5, M6, M7, kmax);
+}
+// the same factors in the layout of the LDS form's y stage (pres_lds4.h, Pres4LdsSolve::F): column = (block row, ky), block row ncolx
+// = the second modes of the threads that carry two; band 3 (the pivots) as reciprocals
+template<class TF>
+__global__ void __launch_bounds__(64) pres4_lds_factor_kernel(TF* __restrict__ F, const TF* __restrict__ bmati, const TF* __restrict__ bmatj,
+                                                  const TF* __restrict__ M1, const TF* __restrict__ M2, const TF* __restrict__ M3, const TF* __restrict__ M4,
+                                                  const TF* __restrict__ M5, const TF* __restrict__ M6, const TF* __restrict__ M7,
+                                                  int ncolx, int jtot, int kmax)
+{
+    const int ky = blockIdx.x*64 + threadIdx.x, row = blockIdx.y;          // rows 0 .. ncolx
+    if (ky >= jtot) return;
+    const int kxa = (row == ncolx) ? ncolx : lds_fft::lds_mode_kx(row, ky, jtot, ncolx);
+    const size_t wlev = (size_t)(ncolx + 1)*jtot, bstride = (size_t)(kmax+4)*wlev;
+    TF* Fc = F + (size_t)row*jtot + ky;
+    // (thread ky > N/2 of block 0 solves mode (itot/2, N - ky); bmatj is even in ky)
+    hdma_factor_column(Fc, wlev, bstride, bmati[kxa], bmatj[ky], row == 0 && ky == 0, M1, M2, M3, M4, M5, M6, M7, kmax);
+    for (int r=0; r<kmax+4; ++r) Fc[3*bstride + (size_t)r*wlev] = TF(1.) / Fc[3*bstride + (size_t)r*wlev];
 }
 
 static int hdma_factor(mhh_pres_plan* P)
@@ -925,6 +947,9 @@ static lds_fft::PresLdsSolve<TF> lds_solve_args(const mhh_pres_plan* P)
 template<class TF, int NX> static const void* lds_kernel_in()  { return reinterpret_cast<const void*>(&lds_fft::pres_in_fftx_kernel<TF, LDS_RG, (NX ? (2 << NX) : LDS_XS), NX>); }
 template<class TF, int NX> static const void* lds_kernel_out() { return reinterpret_cast<const void*>(&lds_fft::pres_ifftx_out_kernel<TF, LDS_RG, (NX ? (2 << NX) : LDS_XS), NX>); }
 template<class TF, int NY> static const void* lds_kernel_y()   { return reinterpret_cast<const void*>(&lds_fft::pres_ysolve_kernel<TF, (NY ? (1 << NY) : LDS_YS), NY>); }
+template<class TF, int NX> static const void* lds4_kernel_in()  { return reinterpret_cast<const void*>(&lds_fft::pres4_in_fftx_kernel<TF, (NX ? (2 << NX) : LDS_XS), NX>); }
+template<class TF, int NX> static const void* lds4_kernel_out() { return reinterpret_cast<const void*>(&lds_fft::pres4_ifftx_out_kernel<TF, (NX ? (2 << NX) : LDS_XS), NX>); }
+template<class TF, int NY> static const void* lds4_kernel_y()   { return reinterpret_cast<const void*>(&lds_fft::pres4_ysolve_kernel<TF, (NY ? (1 << NY) : LDS_YS), NY>); }
 // once per process and kernel: the dynamic-LDS ceiling at the device's maximum (the attribute belongs to the FUNCTION, not to a
 // plan: set per plan to that plan's bytes, a small plan created after a large one lowered the ceiling under the large one), and
 // whether the instantiation needs scratch
@@ -949,14 +974,28 @@ static int pres_lds_kernels_ready(const mhh_pres_plan* P, bool& usable)
 {
     const int nx = ilog2(P->itot/2), ny = ilog2(P->jtot);
     const void* k[3] = {nullptr, nullptr, nullptr};
-    if (P->itot <= LDS_XS) { k[0] = lds_kernel_in<TF, 0>(); k[1] = lds_kernel_out<TF, 0>(); }
-    if (P->jtot <= LDS_YS) k[2] = lds_kernel_y<TF, 0>();
+    if (P->order == 2)
+    {
+        if (P->itot <= LDS_XS) { k[0] = lds_kernel_in<TF, 0>(); k[1] = lds_kernel_out<TF, 0>(); }
+        if (P->jtot <= LDS_YS) k[2] = lds_kernel_y<TF, 0>();
 #define M(N) if (nx == N) { k[0] = lds_kernel_in<TF, N>(); k[1] = lds_kernel_out<TF, N>(); }
-    MHH_FOR_NX(M)
+        MHH_FOR_NX(M)
 #undef M
 #define M(N) if (ny == N) { if constexpr (lds_has_ny<TF, N>()) k[2] = lds_kernel_y<TF, N>(); }
-    MHH_FOR_NY(M)
+        MHH_FOR_NY(M)
 #undef M
+    }
+    else
+    {
+        if (P->itot <= LDS_XS) { k[0] = lds4_kernel_in<TF, 0>(); k[1] = lds4_kernel_out<TF, 0>(); }
+        if (P->jtot <= LDS_YS) k[2] = lds4_kernel_y<TF, 0>();
+#define M(N) if (nx == N) { k[0] = lds4_kernel_in<TF, N>(); k[1] = lds4_kernel_out<TF, N>(); }
+        MHH_FOR_NX(M)
+#undef M
+#define M(N) if (ny == N) { if constexpr (lds_has_ny<TF, N>()) k[2] = lds4_kernel_y<TF, N>(); }
+        MHH_FOR_NY(M)
+#undef M
+    }
     usable = true;
     for (int n=0; n<3; ++n)
     {
@@ -984,8 +1023,17 @@ static int pres_lds_setup_t(mhh_pres_plan* P)
         if (n >= 4) { t[n/2] = 0; t[n/2+1] = -1; t[3*n/2] = 0; t[3*n/2+1] = 1; }
         if (int e = upload(d ? &P->ty : &P->tx, t)) return e;
     }
-    MHH_HIP_TRY(hipMalloc(&P->w3l, (size_t)(P->itot/2 + 1)*P->jtot*P->ktot*sizeof(TF)));
-    hipLaunchKernelGGL(lds_fft::pres_lds_factor_kernel<TF>, dim3((P->jtot + 63)/64, P->itot/2 + 1), dim3(64), 0, 0, static_cast<TF*>(P->w3l), lds_solve_args<TF>(P));
+    if (P->order == 2)
+    {
+        MHH_HIP_TRY(hipMalloc(&P->w3l, (size_t)(P->itot/2 + 1)*P->jtot*P->ktot*sizeof(TF)));
+        hipLaunchKernelGGL(lds_fft::pres_lds_factor_kernel<TF>, dim3((P->jtot + 63)/64, P->itot/2 + 1), dim3(64), 0, 0, static_cast<TF*>(P->w3l), lds_solve_args<TF>(P));
+    }
+    else
+    {   // the 7 factored bands once more, in the column order of this form's y stage (the staged form keeps its own in P->work)
+        MHH_HIP_TRY(hipMalloc(&P->w3l, (size_t)7*(P->ktot + 4)*(P->itot/2 + 1)*P->jtot*sizeof(TF)));
+        hipLaunchKernelGGL(pres4_lds_factor_kernel<TF>, dim3((P->jtot + 63)/64, P->itot/2 + 1), dim3(64), 0, 0, static_cast<TF*>(P->w3l), cp<TF>(P->bmati), cp<TF>(P->bmatj),
+                           cp<TF>(P->m[0]), cp<TF>(P->m[1]), cp<TF>(P->m[2]), cp<TF>(P->m[3]), cp<TF>(P->m[4]), cp<TF>(P->m[5]), cp<TF>(P->m[6]), P->itot/2, P->jtot, P->ktot);
+    }
     MHH_LAUNCH_CHECK();
     MHH_HIP_TRY(hipStreamSynchronize(0));
     P->lds_ok = true;
@@ -995,7 +1043,7 @@ static int pres_lds_setup(mhh_pres_plan* P, const mhh_grid* g)
 {
     const size_t lds_max = 160*1024;
     if (!(is_pow2(P->itot) && P->itot >= 16 && P->itot <= 1024 && is_pow2(P->jtot) && P->jtot >= 8 && P->jtot <= 1024)) return MHH_OK;
-    if (lds_bytes_x(P, 9) > lds_max || lds_bytes_y(P) > lds_max) return MHH_OK;
+    if (lds_bytes_x(P, P->order == 2 ? 9 : 11) > lds_max || lds_bytes_y(P) > lds_max) return MHH_OK;
     if (g->igc > P->itot || g->jgc > P->jtot) return MHH_OK;
     if ((long long)g->icells*g->jcells*g->kcells >= (1ll << 31)) return MHH_OK;        // the x-stage kernels index cells with 32 bits
     return (P->dtype == MHH_F64) ? pres_lds_setup_t<double>(P) : pres_lds_setup_t<float>(P);
@@ -1008,17 +1056,77 @@ static int lds_levels_per_block(const mhh_pres_plan* P)
     if (!e) kc = kc < 4 ? 4 : (kc > 32 ? 32 : kc);
     return kc < 1 ? 1 : (kc > P->ktot ? P->ktot : kc);
 }
+// Pres_4::output's correction of wt (src/pres_4.cxx:565-569; k = kstart is skipped) from p with its ghost levels in place: the
+// part of the LDS form's last stage that needs the level above (pres_lds4.h)
+template<class TF>
+struct Pres4WtOp
+{
+    GridDev<TF> g; const TF* __restrict__ p; TF* __restrict__ wt;
+    __device__ void operator()(int, int, int k, int c) const
+    {
+        const int kk = g.ijcells;
+        wt[c] -= cg4(p[c-2*kk], p[c-kk], p[c], p[c+kk]) * g.dzhi4[k];
+    }
+};
+static int pres4_lds_stage(mhh_pres_plan* P, const mhh_grid* g, const mhh_fields* f, double dt, int stage, dim3 xgrid, int kc, hipStream_t st)
+{
+    const int nx = ilog2(P->itot/2), ny = ilog2(P->jtot);
+    if (stage == 1)
+    {
+        MHH_REQUIRE(f && f->u && f->v && f->w && f->ut && f->vt && f->wt, "null field");
+        MHH_REQUIRE(dt > 0., "dt");
+        if (int e = pres_input_halos(g, 4, f, st)) return e;
+#define M(TF, N) else if (nx == N) hipLaunchKernelGGL((lds_fft::pres4_in_fftx_kernel<TF, (2 << N), N>), xgrid, dim3(P->itot), lds_bytes_x(P, 8), st, a);
+#define CALL(TF) [&]{ lds_fft::Pres4LdsIn<TF> a{make_grid<TF>(g), cp<TF>(f->u), cp<TF>(f->v), cp<TF>(f->w), cp<TF>(f->ut), cp<TF>(f->vt), cp<TF>(f->wt), \
+                          TF(1.)/TF(dt), static_cast<C2<TF>*>(P->spec), static_cast<const C2<TF>*>(P->tx), nx, kc}; \
+                      if (P->itot <= LDS_XS) hipLaunchKernelGGL((lds_fft::pres4_in_fftx_kernel<TF, LDS_XS, 0>), xgrid, dim3(P->itot), lds_bytes_x(P, 8), st, a); \
+                      MHH_FOR_NX_T(M, TF) return MHH_OK; }()
+        if (int e = MHH_DISPATCH(g, CALL)) return e;
+#undef CALL
+#undef M
+    }
+    else if (stage == 2)
+    {
+#define M(TF, N) else if (ny == N) { if constexpr (lds_has_ny<TF, N>()) hipLaunchKernelGGL((lds_fft::pres4_ysolve_kernel<TF, (1 << N), N>), yg, yb, yl, st, ya); }
+#define CALL(TF) [&]{ const dim3 yg(P->itot/2), yb(P->jtot); const size_t yl = lds_bytes_y(P); \
+                      const lds_fft::Pres4LdsSolve<TF> ya{static_cast<C2<TF>*>(P->spec), cp<TF>(P->w3l), static_cast<const C2<TF>*>(P->ty), P->itot/2, P->jtot, ny, P->ktot}; \
+                      if (P->jtot <= LDS_YS) hipLaunchKernelGGL((lds_fft::pres4_ysolve_kernel<TF, LDS_YS, 0>), yg, yb, yl, st, ya); \
+                      MHH_FOR_NY_T(M, TF) return MHH_OK; }()
+        if (int e = MHH_DISPATCH(g, CALL)) return e;
+#undef CALL
+#undef M
+    }
+    else
+    {
+        MHH_REQUIRE(f && f->p && f->ut && f->vt && f->wt, "null field");
+#define M(TF, N) else if (nx == N) hipLaunchKernelGGL((lds_fft::pres4_ifftx_out_kernel<TF, (2 << N), N>), xgrid, dim3(P->itot), lds_bytes_x(P, 11), st, a);
+#define CALL(TF) [&]{ lds_fft::Pres4LdsOut<TF> a{make_grid<TF>(g), static_cast<const C2<TF>*>(P->spec), static_cast<const C2<TF>*>(P->tx), \
+                          mp<TF>(f->p), mp<TF>(f->ut), mp<TF>(f->vt), nx, kc}; \
+                      if (P->itot <= LDS_XS) hipLaunchKernelGGL((lds_fft::pres4_ifftx_out_kernel<TF, LDS_XS, 0>), xgrid, dim3(P->itot), lds_bytes_x(P, 11), st, a); \
+                      MHH_FOR_NX_T(M, TF) return MHH_OK; }()
+        if (int e = MHH_DISPATCH(g, CALL)) return e;
+#undef CALL
+#undef M
+        MHH_LAUNCH_CHECK();
+#define CALL(TF) [&]{ const GridDev<TF> gd = make_grid<TF>(g); Pres4WtOp<TF> op{gd, cp<TF>(f->p), mp<TF>(f->wt)}; return launch_interior(st, gd, g->kstart + 1, g->kend, op); }()
+        if (int e = MHH_DISPATCH(g, CALL)) return e;
+#undef CALL
+    }
+    MHH_LAUNCH_CHECK();
+    return MHH_OK;
+}
 // the three stages, also callable one by one (tests): 1 = input + x transform, 2 = y transforms + Thomas, 3 = x transform + p + output
 MHH_API int mhh_pres_lds_stage(mhh_pres_plan* P, const mhh_grid* g, const mhh_fields* f, double dt, int stage, void* stream)
 {
     if (int e = check_grid(g)) return e;
-    MHH_REQUIRE(P && P->lds_ok, "plan has no LDS-transform form (pres_2, power-of-two itot and jtot)");
+    MHH_REQUIRE(P && P->lds_ok, "plan has no LDS-transform form (power-of-two itot and jtot)");
     MHH_REQUIRE(P->dtype == g->dtype && P->itot == g->itot && P->jtot == g->jtot && P->ktot == g->ktot && g->npy == 1, "plan/grid mismatch");
     MHH_REQUIRE(stage >= 1 && stage <= 3, "stage");
     hipStream_t st = as_stream(stream);
     const int kc = lds_levels_per_block(P);
     const dim3 xgrid((unsigned)(P->jtot/8) * (unsigned)((P->ktot + kc-1)/kc));        // strips x chunks, decoded by lds_strip_of_block
     const int nx = ilog2(P->itot/2), ny = ilog2(P->jtot);
+    if (P->order == 4) return pres4_lds_stage(P, g, f, dt, stage, xgrid, kc, st);
     if (stage == 1)
     {
         MHH_REQUIRE(f && f->u && f->v && f->w && f->ut && f->vt && f->wt && f->rhoref && f->rhorefh, "null field");

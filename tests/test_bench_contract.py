@@ -43,12 +43,12 @@ def test_bench_json_line(world):
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"]/r["peak"]) < 1e-12
     c = d["self_check"]             # the (distributed) solve did its job on the benchmark's own fields: div(u/dt + ut) gone
-    assert c["max_abs_div_of_u_over_dt"] > 1e-3 and c["ratio"] < 1e-12, c
+    assert c["max_abs_pres_input_of_u_over_dt"] > 1e-3 and c["ratio"] < 1e-9, c
 
 
 def test_bench_overlapped_path_two_ranks():
     d = _run(2, extra=[])                                 # default with more than one rank: the halo exchange overlaps the interior rows
-    assert d["config"]["halo_overlap"] is True and d["value"] > 0 and d["self_check"]["ratio"] < 1e-12
+    assert d["config"]["halo_overlap"] is True and d["value"] > 0 and d["self_check"]["ratio"] < 1e-9
     env_was = os.environ.get("MHH_OVERLAP")
     os.environ["MHH_OVERLAP"] = "0"
     try:

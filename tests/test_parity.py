@@ -573,6 +573,89 @@ def test_pres2_lds_transform_form(be, dtype):
     be.lib.mhh_pres_plan_destroy(plan)
 
 
+def _lds4_form_against_oracle(be, shape, dtype, tol, kc=None, stages=False):
+    """Pres_4::exec in the LDS-transform form (csrc/pres_lds4.h) on one grid against the oracle's input -> solve -> output: p with
+    its periodic halo and its four mirrored ghost levels, the three corrected tendencies, the ghost-cell side effects of
+    Pres_4::input; stages=True also runs the three stages one by one (same bits) and checks stage 1 against numpy's transform."""
+    O = cm.oracle()
+    g = cm.grid_4th(*shape, dtype=dtype)
+    c = cm.Case(g, rho="one", periodic=True)
+    for m in (1, 2):
+        c.w[g.kstart-m] = -c.w[g.kstart+m]; c.w[g.kend+m] = -c.w[g.kend-m]
+    Gh = g.host_struct(); dt = 0.7
+    d = B.DevCase(be, c); f = d.fields()
+    plan = capi.PLAN()
+    B.ok(be, be.lib.mhh_pres_plan_create(Gh, 4, ptr(g.dz), ptr(g.dzhi), ptr(g.dzi4), ptr(g.dzhi4), ptr(c.rhoref), ptr(c.rhorefh), C.byref(plan)))
+    if kc: os.environ["MHH_PRES_LDS_KC"] = kc
+    try:
+        assert be.lib.mhh_pres_plan_has_lds_form(plan) == 1, shape
+        os.environ["MHH_PRES_LDS"] = "1"
+        try:
+            assert be.lib.mhh_pres_exec_form(plan) == 1
+            B.ok(be, be.lib.mhh_pres_exec(plan, d.G, C.byref(f), dt, be.stream))
+        finally:
+            os.environ.pop("MHH_PRES_LDS", None)
+        pk = np.zeros((g.ktot, g.jtot, g.itot), dtype=dtype); p_want = np.zeros(g.shape3, dtype=dtype)
+        ut, vt, wt = c.ut.copy(), c.vt.copy(), c.wt.copy()
+        O.orc_pres_input(Gh, 4, ptr(pk), ptr(c.u), ptr(c.v), ptr(c.w), ptr(ut), ptr(vt), ptr(wt), ptr(c.rhoref), ptr(c.rhorefh), dbl(dt))
+        pk_in = pk.copy()
+        O.orc_pres_solve(Gh, 4, ptr(p_want), ptr(pk), ptr(c.rhoref), ptr(c.rhorefh))
+        O.orc_pres_output(Gh, 4, ptr(ut), ptr(vt), ptr(wt), ptr(p_want))
+        sl = (slice(g.kstart-2, g.kend+2), slice(None), slice(None))
+        pscale = np.abs(p_want).max()
+        err = np.abs(be.host(d.p)[sl] - p_want[sl]).max() / pscale
+        assert err <= tol, (shape, err)
+        for got_t, want_t, nm in ((d.ut, ut, "ut"), (d.vt, vt, "vt"), (d.wt, wt, "wt")):
+            terr = np.abs(be.host(got_t) - want_t).max() / max(np.abs(want_t).max(), pscale/float(min(g.dx, g.dy)))
+            assert terr <= 10*tol, (shape, nm, terr)
+        if stages:
+            d2 = B.DevCase(be, c); f2 = d2.fields()
+            B.ok(be, be.lib.mhh_pres_lds_stage(plan, d2.G, C.byref(f2), dt, 1, be.stream)); be.sync()
+            nh = g.itot // 2
+            spec = be.host(be.view(be.lib.mhh_pres_plan_spectral(plan), (g.ktot, nh, g.jtot, 2), dtype))
+            want = np.fft.rfft(pk_in.astype(np.float64), axis=2).transpose(0, 2, 1)
+            got = spec[..., 0] + 1j*spec[..., 1]
+            scale = np.abs(want).max()
+            assert np.abs(got[:, 1:] - want[:, 1:nh]).max() <= tol*scale
+            assert np.abs(got[:, 0].real - want[:, 0].real).max() <= tol*scale and np.abs(got[:, 0].imag - want[:, nh].real).max() <= tol*scale
+            B.ok(be, be.lib.mhh_pres_lds_stage(plan, d2.G, C.byref(f2), dt, 2, be.stream))
+            B.ok(be, be.lib.mhh_pres_lds_stage(plan, d2.G, C.byref(f2), dt, 3, be.stream))
+            for x, y in ((d.p, d2.p), (d.ut, d2.ut), (d.vt, d2.vt), (d.wt, d2.wt)):
+                assert same(be.host(x), be.host(y))
+            # a projection: nothing left for a second solve
+            pk2 = be.zeros((g.ktot, g.jtot, g.itot), dtype)
+            B.ok(be, be.lib.mhh_pres_input(plan, d2.G, C.byref(f2), dt, be.ptr(pk2), be.stream))
+            assert np.abs(be.host(pk2)).max() <= (1e-9 if dtype == np.float64 else 2e-2) * np.abs(pk_in).max()
+    finally:
+        os.environ.pop("MHH_PRES_LDS_KC", None)
+        be.lib.mhh_pres_plan_destroy(plan)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pres4_lds_transform_form(be, dtype):
+    """Pres_4::exec as three kernels with the transforms in LDS + the wt pass (csrc/pres_lds4.h): run-time-size and compile-time-size
+    instantiations, levels-per-block that do and do not divide kmax, kmax not a multiple of the eight levels of a round."""
+    tol = 1e-11 if dtype == np.float64 else 2e-4
+    for shape, kc in (((16, 8, 8), None), ((32, 16, 13), "3"), ((64, 8, 9), "4"), ((16, 64, 17), None), ((128, 32, 6), "2")):
+        _lds4_form_against_oracle(be, shape, dtype, tol, kc=kc, stages=True)
+    # grids the form does not cover keep the staged one
+    g = cm.grid_4th(12, 10, 8, dtype=dtype); c = cm.Case(g, rho="one", periodic=True)
+    plan = capi.PLAN()
+    B.ok(be, be.lib.mhh_pres_plan_create(g.host_struct(), 4, ptr(g.dz), ptr(g.dzhi), ptr(g.dzi4), ptr(g.dzhi4), ptr(c.rhoref), ptr(c.rhorefh), C.byref(plan)))
+    assert be.lib.mhh_pres_plan_has_lds_form(plan) == 0
+    be.lib.mhh_pres_plan_destroy(plan)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pres4_lds_form_at_instantiated_row_lengths(dtype):
+    """The compile-time-size instantiations of the pres_4 kernels against the oracle, moser600's among them (512 x 256, fp64)."""
+    be = B.get("hip")
+    tol = 1e-11 if dtype == np.float64 else 2e-4
+    for shape in [(512, 256, 12), (256, 128, 9), (128, 64, 10), (1024, 512, 8), (256, 512, 8)]:
+        _lds4_form_against_oracle(be, shape, dtype, tol)
+
+
 def _lds_form_against_oracle(be, shape, gc, dtype, tol):
     """Pres_2::exec in the LDS-transform form on one grid against the oracle's input -> solve -> output."""
     O = cm.oracle()
