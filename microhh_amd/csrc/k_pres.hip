@@ -935,7 +935,8 @@ template<class TF, int NY> static constexpr bool lds_has_ny() { return sizeof(TF
 static constexpr int LDS_XS = 64, LDS_YS = 32;            // block sizes of the run-time-size forms (itot <= 64, jtot <= 32)
 static int ilog2(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
 // rows of the transforms + the twiddle table; the 9-row kernel (stage 3) also keeps p of the level below there (8 rows of itot reals)
-static size_t lds_bytes_x(const mhh_pres_plan* P, int rows) { return ((size_t)rows*(P->itot/2 + 2) + P->itot) * 2*P->esz + (rows == 9 ? (size_t)8*P->itot*P->esz : 0); }
+// (pres_4: its 8-row kernel keeps a carried level there, its 11-row kernel nothing)
+static size_t lds_bytes_x(const mhh_pres_plan* P, int rows) { return ((size_t)rows*(P->itot/2 + 2) + P->itot) * 2*P->esz + ((rows == 9 || (rows == 8 && P->order == 4)) ? (size_t)8*P->itot*P->esz : 0); }
 static size_t lds_bytes_y(const mhh_pres_plan* P)           { return ((size_t)8*P->jtot + P->jtot) * 2*P->esz; }
 template<class TF>
 static lds_fft::PresLdsSolve<TF> lds_solve_args(const mhh_pres_plan* P)
@@ -1043,7 +1044,7 @@ static int pres_lds_setup(mhh_pres_plan* P, const mhh_grid* g)
 {
     const size_t lds_max = 160*1024;
     if (!(is_pow2(P->itot) && P->itot >= 16 && P->itot <= 1024 && is_pow2(P->jtot) && P->jtot >= 8 && P->jtot <= 1024)) return MHH_OK;
-    if (lds_bytes_x(P, P->order == 2 ? 9 : 11) > lds_max || lds_bytes_y(P) > lds_max) return MHH_OK;
+    if (lds_bytes_x(P, P->order == 2 ? 9 : 11) > lds_max || lds_bytes_x(P, 8) > lds_max || lds_bytes_y(P) > lds_max) return MHH_OK;
     if (g->igc > P->itot || g->jgc > P->jtot) return MHH_OK;
     if ((long long)g->icells*g->jcells*g->kcells >= (1ll << 31)) return MHH_OK;        // the x-stage kernels index cells with 32 bits
     return (P->dtype == MHH_F64) ? pres_lds_setup_t<double>(P) : pres_lds_setup_t<float>(P);

@@ -34,8 +34,8 @@ struct Pres4LdsIn
     int kc;                           // levels per block
 };
 template<class TF, int BT, int NX>
-// (second launch bound = waves per SIMD the register budget is set for: the carried levels and the window of v need ~150 registers in fp64)
-__global__ void __launch_bounds__(BT, (BT >= 128 ? (sizeof(TF) == 8 ? 2 : 4) : 1)) pres4_in_fftx_kernel(const Pres4LdsIn<TF> a)
+// (second launch bound = waves per SIMD the register budget is set for: a block of 512 threads is two waves per SIMD, so two blocks per CU need four)
+__global__ void __launch_bounds__(BT, (BT >= 128 ? 4 : 1)) pres4_in_fftx_kernel(const Pres4LdsIn<TF> a)
 {
     HIP_DYNAMIC_SHARED(LdsUnit, lds_raw);
     const GridDev<TF>& g = a.g;
@@ -56,16 +56,24 @@ __global__ void __launch_bounds__(BT, (BT >= 128 ? (sizeof(TF) == 8 ? 2 : 4) : 1
     auto U = [&](int c) { return a.ut[c] + a.u[c] * a.dti; };
     auto V = [&](int c) { return a.vt[c] + a.v[c] * a.dti; };
     auto W = [&](int c) { return a.wt[c] + a.w[c] * a.dti; };
-    // the vertical stencil of level k+1 shares three of its four levels with level k: carried
-    TF wm[8], wc[8], wp[8];
+    // the vertical stencil of level k+1 shares three of its four levels with level k: carried, two in registers and the third in
+    // LDS (eight rows of this thread's column; in registers too, the itot = 512 kernel needs scratch at the 128 registers that
+    // let two blocks share a CU)
+    TF wm[8], wc[8];
+    TF* const above0 = reinterpret_cast<TF*>(T + itot);              // row r of this column at above0[r*itot + tid]
     {
         const int c = c0 + (k0 + g.kgc)*kk;
 #pragma unroll
-        for (int r=0; r<8; ++r) { wm[r] = W(c + r*jj - kk); wc[r] = W(c + r*jj); wp[r] = W(c + r*jj + kk); }
+        for (int r=0; r<8; ++r) { wm[r] = W(c + r*jj - kk); wc[r] = W(c + r*jj); above0[r*itot + tid] = W(c + r*jj + kk); }
     }
     for (int k=k0; k<k1; ++k)
     {
-        const int kd = k + g.kgc, c = c0 + kd*kk;
+        // opaque per-level copies of the thread's indices: their address arithmetic stays inside the level instead of being hoisted
+        // out of the loop into registers that are then spilled (see pres_ifftx_out_kernel)
+        unsigned tl = (unsigned)tid, ll = (unsigned)l, sl = (unsigned)(active ? slot : 0), cl = (unsigned)c0;
+        keep_vgpr(tl); keep_vgpr(ll); keep_vgpr(sl); keep_vgpr(cl);
+        const int kd = k + g.kgc, c = (int)cl + kd*kk;
+        TF* const above = above0 + tl;
         const TF dzi4 = uniform_load(g.dzi4, kd);
         // this column's U of the eight rows -> LDS (element x of a row at x + 1, x = -1 .. itot + 1: the three ghost columns the
         // stencil reaches are read from the ghost cells, like the reference does, by the first two threads)
@@ -81,25 +89,28 @@ __global__ void __launch_bounds__(BT, (BT >= 128 ? (sizeof(TF) == 8 ? 2 : 4) : 1
 #pragma unroll
             for (int r=0; r<8; ++r) Dr[r*rs] = U(c + r*jj - 1);
         }
-        // the y and z terms of pres4_in (cell_ops.h; src/pres_4.cxx:305-316) from this thread's own loads, four rows at a time
+        sched_fence();
+        // the y and z terms of pres4_in (cell_ops.h; src/pres_4.cxx:305-316) from this thread's own loads, a few rows at a time
         // (the loads of a group in flight together; few values alive across the barrier: the kernel must fit 128 registers at
         // itot = 1024)
         TF d[8];
+        constexpr int RG = (sizeof(TF) == 8) ? 2 : 4;      // rows per group (fp64: the itot = 512 kernel spills with four)
 #pragma unroll
-        for (int h=0; h<8; h+=4)
+        for (int h=0; h<8; h+=RG)
         {
-            TF vv[7], wn[4];
+            TF vv[RG+3], wn[RG];
 #pragma unroll
-            for (int r=0; r<7; ++r) vv[r] = g.dim3 ? V(c + (h + r - 1)*jj) : TF(0);
+            for (int r=0; r<RG+3; ++r) vv[r] = V(c + (h + r - 1)*jj);          // (jtot >= 8 in this form: the y terms always exist)
 #pragma unroll
-            for (int r=0; r<4; ++r) wn[r] = W(c + (h + r)*jj + 2*kk);
+            for (int r=0; r<RG; ++r) wn[r] = W(c + (h + r)*jj + 2*kk);
 #pragma unroll
-            for (int r=0; r<4; ++r)
+            for (int r=0; r<RG; ++r)
             {
-                TF s = cg4(wm[h+r], wc[h+r], wp[h+r], wn[r]) * dzi4;
-                if (g.dim3) s = cg4(vv[r], vv[r+1], vv[r+2], vv[r+3]) * g.dyi_d + s;
+                const TF wp = above[(h+r)*itot];
+                TF s = cg4(wm[h+r], wc[h+r], wp, wn[r]) * dzi4;
+                s = cg4(vv[r], vv[r+1], vv[r+2], vv[r+3]) * g.dyi_d + s;
                 d[h+r] = s;
-                wm[h+r] = wc[h+r]; wc[h+r] = wp[h+r]; wp[h+r] = wn[r];
+                wm[h+r] = wc[h+r]; wc[h+r] = wp; above[(h+r)*itot] = wn[r];
             }
             sched_fence();
         }
@@ -114,7 +125,6 @@ __global__ void __launch_bounds__(BT, (BT >= 128 ? (sizeof(TF) == 8 ? 2 : 4) : 1
 #pragma unroll
         for (int r=0; r<8; ++r) Dr[2*(r*rp + lds_slot<TF>(tid >> 1)) + (tid & 1)] = d[r];
         lds_barrier();
-        unsigned tl = (unsigned)tid, ll = (unsigned)l, sl = (unsigned)(active ? slot : 0); keep_vgpr(tl); keep_vgpr(ll); keep_vgpr(sl);
         { const C2<TF> none[fft_np(NX)][7] = {}; fft_batch_ct<-1, true, NX, false>(D + sl*rp, T, 1, (int)ll, a.nx, active, none); }
         lds_barrier();
         // real-to-complex as in pres_in_fftx_kernel: rows fastest, (X_0, X_nyq) share column 0
@@ -432,7 +442,7 @@ __global__ void __launch_bounds__(BT, (BT >= 128 ? 4 : 1)) pres4_ifftx_out_kerne
             const TF pn = Dr[2*((r+1)*rp) + oc] * nrm;
             const TF pw1 = Dr[2*(r*rp) + o1] * nrm, pw2 = Dr[2*(r*rp) + o2] * nrm, pe = Dr[2*(r*rp) + oe] * nrm;
             a.ut[cr] -= cg4(pw2, pw1, pc, pe) * g.dxi_d;
-            if (g.dim3) a.vt[cr] -= cg4(pm2, pm1, pc, pn) * g.dyi_d;
+            a.vt[cr] -= cg4(pm2, pm1, pc, pn) * g.dyi_d;                    // (jtot >= 8 in this form)
             // p: the cell, its images in the periodic halo, on its own level and on the ghost levels that mirror it
             const int js = j0 + qd;
             for (int lv=0; lv<nl; ++lv)
