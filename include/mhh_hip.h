@@ -271,11 +271,12 @@ int  mhh_pres_plan_create(const mhh_grid* g, int order /*2|4*/,
 void mhh_pres_plan_destroy(mhh_pres_plan* plan);
 /* Pres::exec(dt): input -> solve -> output (src/pres_2.cxx:66-94, pres_4.cxx:64-140) */
 int mhh_pres_exec(mhh_pres_plan* plan, const mhh_grid* g, const mhh_fields* f, double dt, void* stream);
-/* pres_2 with power-of-two itot, jtot: three kernels that do the transforms in LDS (csrc/pres_lds.h) instead of the seven
- * passes of the staged form. mhh_pres_exec takes this form on large grids (>= 2^26 cells, itot >= 512: where it is faster on
- * MI355X); MHH_PRES_LDS=1 / 0 selects it wherever the plan has it / never. The stages one by one, for tests:
- * 1 = Pres_2::input + transform along x (src/pres_2.cxx:156-196, src/fft.cxx:451-497), 2 = transforms along y around the
- * Thomas sweeps (src/pres_2.cxx:202-263), 3 = transform back along x + p with ghost cells + Pres_2::output (:333-387).      */
+/* Power-of-two itot, jtot: three kernels that do the transforms in LDS (pres_2: csrc/pres_lds.h, pres_4: csrc/pres_lds4.h) instead
+ * of the seven passes of the staged form. mhh_pres_exec takes this form from 2^24 cells on (where it is faster on MI355X:
+ * profiles/r3_pres_forms.md); MHH_PRES_LDS=1 / 0 selects it wherever the plan has it / never. The stages one by one, for tests:
+ * 1 = Pres::input + transform along x (src/pres_2.cxx:156-196, src/pres_4.cxx:256-317, src/fft.cxx:451-497), 2 = transforms along y
+ * around the k sweeps (Thomas, src/pres_2.cxx:202-263; the factored 7-band system, src/pres_4.cxx:358-470, 574-730), 3 = transform
+ * back along x + p with its ghost cells + Pres::output (src/pres_2.cxx:333-387; src/pres_4.cxx:481-571).                        */
 int   mhh_pres_lds_stage(mhh_pres_plan* plan, const mhh_grid* g, const mhh_fields* f, double dt, int stage, void* stream);
 int   mhh_pres_plan_has_lds_form(const mhh_pres_plan* plan);
 int   mhh_pres_exec_form(const mhh_pres_plan* plan);   /* what mhh_pres_exec will run: 0 = staged (rocFFT), 1 = transforms in LDS */
