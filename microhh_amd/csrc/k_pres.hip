@@ -1069,6 +1069,24 @@ struct Pres4WtOp
         wt[c] -= cg4(p[c-2*kk], p[c-kk], p[c], p[c+kk]) * g.dzhi4[k];
     }
 };
+// the same, one thread per column and chunk of levels with the four levels of p in a sliding window: one read of p per cell (+ three
+// per chunk) where the cell form reads four (0.185 -> see profiles/r3_pres_forms.md at 512 x 256 x 256)
+template<class TF>
+__global__ void __launch_bounds__(256) pres4_wt_march_kernel(const GridDev<TF> g, const TF* __restrict__ p, TF* __restrict__ wt, int kc)
+{
+    const int i = g.istart + blockIdx.x*64 + threadIdx.x, j = g.jstart + blockIdx.y*4 + threadIdx.y;
+    const int k0 = g.kstart + 1 + blockIdx.z*kc, k1 = (k0 + kc < g.kend) ? k0 + kc : g.kend;
+    if (i >= g.iend || j >= g.jend || k0 >= k1) return;
+    const int kk = g.ijcells;
+    int c = i + j*g.icells + k0*kk;
+    TF pm2 = p[c-2*kk], pm1 = p[c-kk], pc = p[c];
+    for (int k=k0; k<k1; ++k, c+=kk)
+    {
+        const TF pn = p[c+kk];
+        wt[c] -= cg4(pm2, pm1, pc, pn) * uniform_load(g.dzhi4, k);
+        pm2 = pm1; pm1 = pc; pc = pn;
+    }
+}
 static int pres4_lds_stage(mhh_pres_plan* P, const mhh_grid* g, const mhh_fields* f, double dt, int stage, dim3 xgrid, int kc, hipStream_t st)
 {
     const int nx = ilog2(P->itot/2), ny = ilog2(P->jtot);
@@ -1090,7 +1108,7 @@ static int pres4_lds_stage(mhh_pres_plan* P, const mhh_grid* g, const mhh_fields
     {
 #define M(TF, N) else if (ny == N) { if constexpr (lds_has_ny<TF, N>()) hipLaunchKernelGGL((lds_fft::pres4_ysolve_kernel<TF, (1 << N), N>), yg, yb, yl, st, ya); }
 #define CALL(TF) [&]{ const dim3 yg(P->itot/2), yb(P->jtot); const size_t yl = lds_bytes_y(P); \
-                      const lds_fft::Pres4LdsSolve<TF> ya{static_cast<C2<TF>*>(P->spec), cp<TF>(P->w3l), static_cast<const C2<TF>*>(P->ty), P->itot/2, P->jtot, ny, P->ktot}; \
+                      const lds_fft::Pres4LdsSolve<TF> ya{static_cast<C2<TF>*>(P->spec), cp<TF>(P->w3l), cp<TF>(P->m[6]), static_cast<const C2<TF>*>(P->ty), P->itot/2, P->jtot, ny, P->ktot}; \
                       if (P->jtot <= LDS_YS) hipLaunchKernelGGL((lds_fft::pres4_ysolve_kernel<TF, LDS_YS, 0>), yg, yb, yl, st, ya); \
                       MHH_FOR_NY_T(M, TF) return MHH_OK; }()
         if (int e = MHH_DISPATCH(g, CALL)) return e;
@@ -1109,9 +1127,21 @@ static int pres4_lds_stage(mhh_pres_plan* P, const mhh_grid* g, const mhh_fields
 #undef CALL
 #undef M
         MHH_LAUNCH_CHECK();
+        const char* wm = getenv("MHH_PRES4_WT");                             // "cell": the one-thread-per-cell form (A/B)
+        if (wm && !strcmp(wm, "cell"))
+        {
 #define CALL(TF) [&]{ const GridDev<TF> gd = make_grid<TF>(g); Pres4WtOp<TF> op{gd, cp<TF>(f->p), mp<TF>(f->wt)}; return launch_interior(st, gd, g->kstart + 1, g->kend, op); }()
-        if (int e = MHH_DISPATCH(g, CALL)) return e;
+            if (int e = MHH_DISPATCH(g, CALL)) return e;
 #undef CALL
+        }
+        else if (g->kmax > 1)
+        {
+            const int wkc = 32;
+            const dim3 wg((g->imax + 63)/64, (g->jmax + 3)/4, (g->kmax - 1 + wkc - 1)/wkc);
+#define CALL(TF) [&]{ hipLaunchKernelGGL(pres4_wt_march_kernel<TF>, wg, dim3(64, 4), 0, st, make_grid<TF>(g), cp<TF>(f->p), mp<TF>(f->wt), wkc); return MHH_OK; }()
+            if (int e = MHH_DISPATCH(g, CALL)) return e;
+#undef CALL
+        }
     }
     MHH_LAUNCH_CHECK();
     return MHH_OK;

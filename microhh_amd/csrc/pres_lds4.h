@@ -154,6 +154,8 @@ struct Pres4LdsSolve
     C2<TF>* S;
     const TF* F;                      // F[(band*(kmax+4) + row)*wlev + col], wlev = (ncol+1)*jtot, col = kx*jtot + ky: the LU factors of
                                       // the mode thread ky of block kx solves (block row ncol: the second modes of "two"); band 3 = 1 / m4
+    const TF* M7;                     // the outermost upper band is the matrix's own on every row the back substitution multiplies by a
+                                      // non-zero (LU without pivoting leaves it alone): per level, not per mode -- read through the scalar cache
     const C2<TF>* Ty;                 // exp(-2 pi i m / jtot)
     int ncol, jtot, ny, kmax;         // ncol = itot/2 columns; ny = log2(jtot)
 };
@@ -277,7 +279,7 @@ __global__ void __launch_bounds__(BT) pres4_ysolve_kernel(const Pres4LdsSolve<TF
     }
     // ---- up: back substitution over eight levels -> LDS -> inverse transform along y -> S
     // (the values this thread reads back are the ones it wrote itself)
-    TF h4[8], h5[8], h6[8], h7[8];
+    TF h4[8], h5[8], h6[8];
     auto request = [&](int k0)
     {
 #pragma unroll
@@ -286,7 +288,7 @@ __global__ void __launch_bounds__(BT) pres4_ysolve_kernel(const Pres4LdsSolve<TF
             const int k = (k0 + m < kmax) ? k0 + m : kmax - 1;
             const size_t r = (size_t)(k + 2)*wlev;
             q[m] = Sc[(size_t)k*lev];
-            h4[m] = Fc[3*band + r]; h5[m] = Fc[4*band + r]; h6[m] = Fc[5*band + r]; h7[m] = Fc[6*band + r];
+            h4[m] = Fc[3*band + r]; h5[m] = Fc[4*band + r]; h6[m] = Fc[5*band + r];
         }
     };
     request((nround-1) << 3);
@@ -294,14 +296,17 @@ __global__ void __launch_bounds__(BT) pres4_ysolve_kernel(const Pres4LdsSolve<TF
     {
         const int k0 = rd << 3;
         C2<TF> o[8];
+        TF h7[8];                          // (row kmax+1, level kmax-1, multiplies x of row kmax+4: zero, whatever the band holds)
+#pragma unroll
+        for (int m=0; m<8; ++m) h7[m] = uniform_load(a.M7, (k0 + m < kmax) ? k0 + m : kmax - 1);
         if (two)
         {
-            TF e4[8], e5[8], e6[8], e7[8];
+            TF e4[8], e5[8], e6[8];
 #pragma unroll
             for (int m=0; m<8; ++m)
             {
                 const size_t r = (size_t)(((k0 + m < kmax) ? k0 + m : kmax - 1) + 2)*wlev;
-                e4[m] = Fc2[3*band + r]; e5[m] = Fc2[4*band + r]; e6[m] = Fc2[5*band + r]; e7[m] = Fc2[6*band + r];
+                e4[m] = Fc2[3*band + r]; e5[m] = Fc2[4*band + r]; e6[m] = Fc2[5*band + r];
             }
 #pragma unroll
             for (int m=7; m>=0; --m)
@@ -310,7 +315,7 @@ __global__ void __launch_bounds__(BT) pres4_ysolve_kernel(const Pres4LdsSolve<TF
                 if (k0 + m < kmax)
                 {
                     r.x = (q[m].x - b1.x*h5[m] - b2.x*h6[m] - b3.x*h7[m]) * h4[m];
-                    r.y = (q[m].y - b1.y*e5[m] - b2.y*e6[m] - b3.y*e7[m]) * e4[m];
+                    r.y = (q[m].y - b1.y*e5[m] - b2.y*e6[m] - b3.y*h7[m]) * e4[m];
                     b3 = b2; b2 = b1; b1 = r;
                 }
                 o[m] = r;

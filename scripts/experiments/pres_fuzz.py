@@ -1,6 +1,6 @@
 """Randomised run of Pres::exec on the GPU against the CPU oracle (input -> spectral solve -> output) on random grid shapes,
 pres_2 and pres_4, both precisions: p and the corrected tendencies within the stated tolerance (1e-11 / 2e-4 of max|p|).
-A third argument "lds" draws power-of-two pres_2 grids and forces the form with the transforms in LDS (csrc/pres_lds.h) with a random
+A third argument "lds" draws power-of-two grids (pres_2 and pres_4) and forces the form with the transforms in LDS (csrc/pres_lds.h) with a random
 number of levels per block; p is then compared with all its ghost cells. Test infrastructure (imports tests/ and oracle/)."""
 import os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,8 +21,8 @@ for it in range(n):
     itot = int(rng.choice([4, 6, 8, 12, 16, 20, 30, 32, 48, 64])); jtot = int(rng.choice([1, 3, 4, 6, 8, 10, 16, 24])); ktot = int(rng.integers(4, 24))
     if lds:
         # every instantiated row length (csrc/k_pres.hip): itot 16 ... 1024, jtot 8 ... 1024 (fp64: ... 512); few levels on the big planes
-        order = 2; itot = int(rng.choice([16, 32, 64, 128, 256, 512, 1024])); jtot = int(rng.choice([8, 16, 32, 64, 128, 256, 512, 1024]))
-        if dtype == np.float64 and jtot == 1024: jtot = 512
+        itot = int(rng.choice([16, 32, 64, 128, 256, 512, 1024])); jtot = int(rng.choice([8, 16, 32, 64, 128, 256, 512, 1024]))
+        if (dtype == np.float64 or order == 4) and jtot == 1024: jtot = 512         # no instantiation (it would need scratch): staged form
         ktot = int(rng.integers(2, 40)) if itot*jtot <= 128*128 else int(rng.integers(2, 9))
         os.environ["MHH_PRES_LDS"] = "1"; os.environ["MHH_PRES_LDS_KC"] = str(int(rng.integers(1, 12)))
     if order == 2:
@@ -50,6 +50,7 @@ for it in range(n):
     if lds:
         assert be.lib.mhh_pres_exec_form(plan) == 1
         sl = (slice(g.kstart-1, g.kend), slice(None), slice(None))          # p with its periodic halo and the ghost level below
+        if order == 4: sl = (slice(g.kstart-2, g.kend+2), slice(None), slice(None))      # ... its four mirrored ghost levels
     tol = 1e-11 if dtype == np.float64 else 2e-4
     scale = np.abs(p_want[sl]).max()
     err = np.abs(be.host(d.p)[sl] - p_want[sl]).max() / scale
