@@ -109,8 +109,27 @@ template<class TF> MHH_HD TF i5(TF a, TF b, TF c, TF d, TF e, TF f)
 template<class TF> MHH_HD TF i4ws(TF a, TF b, TF c, TF d) { return TF(7./12.)*(b+c) - TF(1./12.)*(a+d); }
 template<class TF> MHH_HD TF i3ws(TF a, TF b, TF c, TF d) { return TF(3./12.)*(c-b) - TF(1./12.)*(d-a); }
 
+// Four-point weights, summed left to right as the reference writes them. A product by a power of two is exact (no rounding
+// unless it underflows: |x| < 2^-1018 in fp64), so RN(w*x + t) with such a w is ONE fma with the bits of the multiplication
+// followed by the addition -- an instruction less per such weight (the -1/16 at both ends of the 4th-order interpolation: two of
+// its seven operations, 108 of the ~900 vector instructions per cell of advec_4 + diff_4). The other weights keep their two
+// roundings. F2 (two fp32 cells per lane) keeps the product-sum: its operations are packed instructions.
+constexpr bool w_is_pow2(double w) { double a = w < 0 ? -w : w; if (a == 0) return false; while (a < 1) a *= 2; while (a > 1) a /= 2; return a == 1; }
+template<class TF> MHH_HD TF pw2_fma(double w, TF x, TF t) { return TF(w)*x + t; }
+MHH_HD double pw2_fma(double w, double x, double t) { return __builtin_fma(w, x, t); }
+MHH_HD float  pw2_fma(double w, float x, float t)   { return __builtin_fmaf((float)w, x, t); }
+#ifndef MHH_W4_POW2_FMA
+#define MHH_W4_POW2_FMA 1
+#endif
 #define MHH_W4(name, w0, w1, w2, w3) \
-    template<class TF> MHH_HD TF name(TF a, TF b, TF c, TF d) { return TF(w0)*a + TF(w1)*b + TF(w2)*c + TF(w3)*d; }
+    template<class TF> MHH_HD TF name(TF a, TF b, TF c, TF d) { \
+        TF t; \
+        if constexpr (MHH_W4_POW2_FMA && w_is_pow2(w0))      t = pw2_fma(w0, a, TF(w1)*b); \
+        else if constexpr (MHH_W4_POW2_FMA && w_is_pow2(w1)) t = pw2_fma(w1, b, TF(w0)*a); \
+        else                                                 t = TF(w0)*a + TF(w1)*b; \
+        if constexpr (MHH_W4_POW2_FMA && w_is_pow2(w2)) t = pw2_fma(w2, c, t); else t = t + TF(w2)*c; \
+        if constexpr (MHH_W4_POW2_FMA && w_is_pow2(w3)) t = pw2_fma(w3, d, t); else t = t + TF(w3)*d; \
+        return t; }
 MHH_W4(ci4, -1./16.,  9./16.,  9./16., -1./16.)
 MHH_W4(bi4,  5./16., 15./16., -5./16.,  1./16.)
 MHH_W4(ti4,  1./16., -5./16., 15./16.,  5./16.)
@@ -118,7 +137,7 @@ MHH_W4(cg4,  1./24., -27./24., 27./24., -1./24.)
 MHH_W4(bg4, -23./24., 21./24.,  3./24., -1./24.)
 MHH_W4(tg4,  1./24., -3./24., -21./24., 23./24.)
 #undef MHH_W4
-template<class TF> MHH_HD TF i4c(TF a, TF b, TF c, TF d) { return TF(-1./16.)*(a+d) + TF(9./16.)*(b+c); }
+template<class TF> MHH_HD TF i4c(TF a, TF b, TF c, TF d) { return MHH_W4_POW2_FMA ? pw2_fma(-1./16., a+d, TF(9./16.)*(b+c)) : TF(-1./16.)*(a+d) + TF(9./16.)*(b+c); }
 
 // =======================================================================================================
 // advec_2 (src/advec_2.cxx:81-202). COMP: 0=u 1=v 2=w (momentum, staggering offset o = -1/-jj/-kk), 3=scalar.
