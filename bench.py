@@ -378,6 +378,13 @@ def main():
         "alg_bytes_per_cell_full_step": hp.alg_bytes_rhs() + hp.alg_bytes_visc() + (0 if rhs_only else hp.alg_bytes_pres()),
         "hbm_frac_full_step": (hp.alg_bytes_rhs() + hp.alg_bytes_visc() + (0 if rhs_only else hp.alg_bytes_pres())) * local_cells / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
     }
+    if not rhs_only:
+        # self-check of the solve on the state the timed steps left behind (before anything else launches kernels on these fields) (every rank takes part: halos + MAX over ranks):
+        # Pres::input -- the divergence of u/dt + ut, which Pres::exec has just removed -- beside the same of u, v, w alone
+        comm_events, hp.comm_timing = hp.comm_timing, None        # (the exchanges of the check are not the step's)
+        d1, d0 = hp.projected_divergence()
+        hp.comm_timing = comm_events
+        out["self_check"] = {"max_abs_pres_input_after_pres": d1, "max_abs_pres_input_of_u_over_dt": d0, "ratio": d1 / d0 if d0 else None}
     if not rhs_only and not overlapped and not hp.slab:
         out["pressure"] = {"ms": float(np.mean([e[1].elapsed_time(e[3]) for e in events])),
                            "form": "transforms in LDS, 3 kernels (csrc/pres_lds.h, pres_lds4.h)" if hp.lib.mhh_pres_exec_form(hp.plan) == 1 else "staged, rocFFT (csrc/k_pres.hip)"}
@@ -422,13 +429,6 @@ def main():
                             "frac": alg_bytes / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             "tolerance": "tendency increments within 64 ulp of the field's largest increment of the bit-exact build (tests/test_fma_build.py)"}
         hp2.close()
-    if not rhs_only:
-        # self-check of the solve on the state the timed steps left behind (every rank takes part: halos + MAX over ranks):
-        # Pres::input -- the divergence of u/dt + ut, which Pres::exec has just removed -- beside the same of u, v, w alone
-        comm_events, hp.comm_timing = hp.comm_timing, None        # (the exchanges of the check are not the step's)
-        d1, d0 = hp.projected_divergence()
-        hp.comm_timing = comm_events
-        out["self_check"] = {"max_abs_pres_input_after_pres": d1, "max_abs_pres_input_of_u_over_dt": d0, "ratio": d1 / d0 if d0 else None}
     if not on_gpu:
         out["data"] = "synthetic; CPU REHEARSAL of the script (emulated kernels, gloo): not a measurement"
     if hp.comm_timing:
