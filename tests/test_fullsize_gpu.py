@@ -99,11 +99,11 @@ def test_pressure_step_is_a_projection_at_full_size(case, shape):
     hp.close()
 
 
-@pytest.mark.parametrize("case,shape,tol", [("drycblles", (512, 512, 512), 1e-11), ("gabls1", (1024, 1024, 256), 2e-4)],
-                         ids=["configs3-drycblles512-fp64", "configs4-gabls1-fp32"])
+@pytest.mark.parametrize("case,shape,tol", [("drycblles", (512, 512, 512), 1e-11), ("gabls1", (1024, 1024, 256), 2e-4), ("moser600", (512, 256, 256), 1e-11)],
+                         ids=["configs3-drycblles512-fp64", "configs4-gabls1-fp32", "configs2-moser600-fp64-pres_4"])
 def test_pressure_lds_transform_form_matches_staged_form_at_full_size(case, shape, tol):
-    """Pres_2::exec with the transforms in LDS (three kernels, the form mhh_pres_exec takes by itself at these sizes) against the
-    staged rocFFT form on the same right-hand side: p and the corrected tendencies within the pressure tolerance."""
+    """Pres_2::exec / Pres_4::exec with the transforms in LDS (three kernels, the form mhh_pres_exec takes by itself at these sizes)
+    against the staged rocFFT form on the same right-hand side: p and the corrected tendencies within the pressure tolerance."""
     import torch
     hp = _hp(case, shape, dt=0.5)
     assert hp.lib.mhh_pres_plan_has_lds_form(hp.plan) == 1
