@@ -49,6 +49,7 @@ struct mhh_pres_plan
     bool fft_setup = false;
     // the three-kernel form with the transforms in LDS (pres_lds.h): twiddle tables, w3 in its [k][kx][ky] layout
     void* tx = nullptr; void* ty = nullptr; void* w3l = nullptr;
+    void* a3l = nullptr; void* itw = nullptr; int ksplit = 0; bool tw_ok = false;     // the two-blocks-per-column form of the y stage (pres_2)
     bool lds_ok = false;
     // mhh_pres_exec_rk: the Runge-Kutta sub-step of u, v, w rides in the kernel that stores the corrected tendencies
     bool rk_on = false; double rk_cA = 0, rk_cB = 0, rk_dt = 0; void* rk_u = nullptr; void* rk_v = nullptr; void* rk_w = nullptr;
@@ -193,7 +194,7 @@ MHH_API void mhh_pres_plan_destroy(mhh_pres_plan* P)
     if (P->bwd_info) rocfft_execution_info_destroy(P->bwd_info);
     if (P->fwd_info_cb) rocfft_execution_info_destroy(P->fwd_info_cb);
     if (P->bwd_info_cb) rocfft_execution_info_destroy(P->bwd_info_cb);
-    void* bufs[] = {P->tx, P->ty, P->w3l, P->cb_data, P->bmati, P->bmatj, P->a, P->c, P->dz, P->rhoref, P->packed, P->spec, P->work, P->fwd_wb, P->bwd_wb,
+    void* bufs[] = {P->tx, P->ty, P->w3l, P->a3l, P->itw, P->cb_data, P->bmati, P->bmatj, P->a, P->c, P->dz, P->rhoref, P->packed, P->spec, P->work, P->fwd_wb, P->bwd_wb,
                     P->m[0], P->m[1], P->m[2], P->m[3], P->m[4], P->m[5], P->m[6]};
     for (void* b : bufs) if (b) (void)hipFree(b);
     delete P;
@@ -951,6 +952,7 @@ template<class TF, int NY> static const void* lds_kernel_y()   { return reinterp
 template<class TF, int NX> static const void* lds4_kernel_in()  { return reinterpret_cast<const void*>(&lds_fft::pres4_in_fftx_kernel<TF, (NX ? (2 << NX) : LDS_XS), NX>); }
 template<class TF, int NX> static const void* lds4_kernel_out() { return reinterpret_cast<const void*>(&lds_fft::pres4_ifftx_out_kernel<TF, (NX ? (2 << NX) : LDS_XS), NX>); }
 template<class TF, int NY> static const void* lds4_kernel_y()   { return reinterpret_cast<const void*>(&lds_fft::pres4_ysolve_kernel<TF, (NY ? (1 << NY) : LDS_YS), NY>); }
+template<class TF, int NY, int PH> static const void* lds_kernel_ytw() { return reinterpret_cast<const void*>(&lds_fft::pres_ysolve_tw_kernel<TF, (NY ? (1 << NY) : LDS_YS), NY, PH>); }
 // once per process and kernel: the dynamic-LDS ceiling at the device's maximum (the attribute belongs to the FUNCTION, not to a
 // plan: set per plan to that plan's bytes, a small plan created after a large one lowered the ceiling under the large one), and
 // whether the instantiation needs scratch
@@ -1028,6 +1030,27 @@ static int pres_lds_setup_t(mhh_pres_plan* P)
     {
         MHH_HIP_TRY(hipMalloc(&P->w3l, (size_t)(P->itot/2 + 1)*P->jtot*P->ktot*sizeof(TF)));
         hipLaunchKernelGGL(lds_fft::pres_lds_factor_kernel<TF>, dim3((P->jtot + 63)/64, P->itot/2 + 1), dim3(64), 0, 0, static_cast<TF*>(P->w3l), lds_solve_args<TF>(P));
+        // the two-blocks-per-column form of the y stage: its kernels (no scratch), the factors of the top-down half, the buffer where the halves meet
+        if (P->ktot >= 16)
+        {
+            const int ny = ilog2(P->jtot);
+            const void* k2[2] = {nullptr, nullptr};
+            if (P->jtot <= LDS_YS) { k2[0] = lds_kernel_ytw<TF, 0, 1>(); k2[1] = lds_kernel_ytw<TF, 0, 2>(); }
+#define M(N) if (ny == N) { if constexpr (lds_has_ny<TF, N>()) { k2[0] = lds_kernel_ytw<TF, N, 1>(); k2[1] = lds_kernel_ytw<TF, N, 2>(); } }
+            MHH_FOR_NY(M)
+#undef M
+            bool ok2 = (k2[0] != nullptr);
+            for (int n=0; n<2 && ok2; ++n) { bool u = false; if (int e = lds_kernel_ready(k2[n], u)) return e; ok2 = u; }
+            if (ok2)
+            {
+                P->ksplit = ((P->ktot/2 + 7)/8)*8;
+                MHH_HIP_TRY(hipMalloc(&P->a3l, (size_t)(P->itot/2 + 1)*P->jtot*P->ktot*sizeof(TF)));
+                MHH_HIP_TRY(hipMalloc(&P->itw, (size_t)(P->itot/2)*2*P->jtot*2*sizeof(TF)));
+                const lds_fft::PresLdsSolveTw<TF> ta{lds_solve_args<TF>(P), cp<TF>(P->a3l), static_cast<C2<TF>*>(P->itw), P->ksplit};
+                hipLaunchKernelGGL(lds_fft::pres_lds_factor_tw_kernel<TF>, dim3((P->jtot + 63)/64, P->itot/2 + 1), dim3(64), 0, 0, static_cast<TF*>(P->a3l), ta);
+                P->tw_ok = true;
+            }
+        }
     }
     else
     {   // the 7 factored bands once more, in the column order of this form's y stage (the staged form keeps its own in P->work)
@@ -1048,6 +1071,17 @@ static int pres_lds_setup(mhh_pres_plan* P, const mhh_grid* g)
     if (g->igc > P->itot || g->jgc > P->jtot) return MHH_OK;
     if ((long long)g->icells*g->jcells*g->kcells >= (1ll << 31)) return MHH_OK;        // the x-stage kernels index cells with 32 bits
     return (P->dtype == MHH_F64) ? pres_lds_setup_t<double>(P) : pres_lds_setup_t<float>(P);
+}
+// the y stage with two blocks per column (pres_lds.h, 2t)? MHH_PRES_Y_TWISTED=1 / 0: wherever the plan has it / never
+static bool pres_y_twisted(const mhh_pres_plan* P)
+{
+    if (!P->tw_ok || P->order != 2) return false;
+    const char* e = getenv("MHH_PRES_Y_TWISTED");
+    if (e) return !strcmp(e, "1");
+    // measured on MI355X (profiles/r3_pres_forms.md): with fewer columns than the chip has CUs the stage is a dependent chain per block
+    // and the half-length chains win (itot = 256: 0.245 -> 0.160 ms at 256^3, 0.511 -> 0.390 at 256 x 256 x 512); at itot = 512 there
+    // is a block per CU already and the second launch costs more than it saves (0.93 -> 1.07 ms at 512^3)
+    return P->itot <= 256;
 }
 static int lds_levels_per_block(const mhh_pres_plan* P)
 {
@@ -1168,6 +1202,20 @@ MHH_API int mhh_pres_lds_stage(mhh_pres_plan* P, const mhh_grid* g, const mhh_fi
                           cp<TF>(f->rhoref), cp<TF>(f->rhorefh), TF(1.)/TF(dt), static_cast<C2<TF>*>(P->spec), static_cast<const C2<TF>*>(P->tx), nx, kc, 0, P->ktot, P->jtot, {}}; \
                       if (P->itot <= LDS_XS) hipLaunchKernelGGL((lds_fft::pres_in_fftx_kernel<TF, LDS_RG, LDS_XS, 0>), xgrid, dim3(P->itot), lds_bytes_x(P, 8), st, a); \
                       MHH_FOR_NX_T(M, TF) return MHH_OK; }()
+        if (int e = MHH_DISPATCH(g, CALL)) return e;
+#undef CALL
+#undef M
+    }
+    else if (stage == 2 && pres_y_twisted(P))
+    {
+        // two blocks per column, two launches: eliminate towards the split | solve where the halves meet and substitute outward
+#define M(TF, N) else if (ny == N) { if constexpr (lds_has_ny<TF, N>()) { hipLaunchKernelGGL((lds_fft::pres_ysolve_tw_kernel<TF, (1 << N), N, 1>), yg, yb, yl, st, ya); \
+                                                                          hipLaunchKernelGGL((lds_fft::pres_ysolve_tw_kernel<TF, (1 << N), N, 2>), yg, yb, yl, st, ya); } }
+#define CALL(TF) [&]{ const dim3 yg(P->itot), yb(P->jtot); const size_t yl = lds_bytes_y(P); \
+                      const lds_fft::PresLdsSolveTw<TF> ya{lds_solve_args<TF>(P), cp<TF>(P->a3l), static_cast<C2<TF>*>(P->itw), P->ksplit}; \
+                      if (P->jtot <= LDS_YS) { hipLaunchKernelGGL((lds_fft::pres_ysolve_tw_kernel<TF, LDS_YS, 0, 1>), yg, yb, yl, st, ya); \
+                                               hipLaunchKernelGGL((lds_fft::pres_ysolve_tw_kernel<TF, LDS_YS, 0, 2>), yg, yb, yl, st, ya); } \
+                      MHH_FOR_NY_T(M, TF) return MHH_OK; }()
         if (int e = MHH_DISPATCH(g, CALL)) return e;
 #undef CALL
 #undef M

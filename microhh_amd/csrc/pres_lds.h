@@ -17,6 +17,7 @@
 // reference's transforms are FFTW's; like rocFFT's these agree with them to rounding (DESIGN.md "Parity": the pressure is the
 // toleranced part of the path).
 #pragma once
+#include <type_traits>
 #include <gfx950_prims.h>   // angle form: the CPU emulation build (tests/emul) overrides it by include path
 
 namespace mhh { namespace lds_fft {
@@ -560,6 +561,238 @@ __global__ void __launch_bounds__(BT) pres_ysolve_kernel(const PresLdsSolve<TF> 
         for (int m=0; m<8; ++m) if (k0 + m < kmax) Sc[(size_t)(k0 + m)*lev] = D[m*rp + lds_slot<TF>(ky)];
         lds_barrier();
     }
+}
+
+// ----------------------------------------------------------------------------------------------------------------------
+// (2t) The same stage with TWO blocks per kx (twisted factorisation): the levels [0, ksplit) are eliminated from the bottom up by
+// block 2 kx -- the forward sweep above -- and the levels [ksplit, kmax) from the top down by block 2 kx + 1 (the mirror image: c
+// and a change places, x_k = d''_k - a'_k x_{k-1}); a second launch solves the 2 x 2 system where the two meet
+//     x_{m-1} = d'_{m-1} - c'_{m-1} x_m,   x_m = d''_m - a'_m x_{m-1}      (m = ksplit)
+// and substitutes outward from there, each block through its own levels and back through the transform along y. Same operation
+// count and array passes as the one-block form, half the dependent chain per block, twice the blocks: for grids with fewer columns
+// than the chip has CUs (itot <= 256) and for one block per CU (itot = 512), where a round of eight levels is a chain of barriers
+// and dependent fp64 operations. A different elimination order than the reference's tdma: inside the pressure tolerance
+// (DESIGN.md "Parity"), not the same bits as the one-block form.
+// ----------------------------------------------------------------------------------------------------------------------
+template<class TF>
+struct PresLdsSolveTw
+{
+    PresLdsSolve<TF> s;
+    const TF* A3;                     // A3[k][kx][ky] = a[k] / w2'[k] of the top-down elimination (layout of W3; levels >= ksplit)
+    C2<TF>* I;                        // I[kx][0 | 1][ky]: d' of level ksplit-1 and d'' of level ksplit, as the eliminations leave them -- the second
+                                      // launch reads them here: in S the other block of the column may already have stored its solution over them
+    int ksplit;                       // a multiple of 8, 8 <= ksplit < kmax
+};
+// the pivots of the top-down elimination as reciprocals, the same recurrence as in the sweep (see pres_lds_factor_kernel)
+template<class TF>
+__global__ void __launch_bounds__(64) pres_lds_factor_tw_kernel(TF* __restrict__ A3, const PresLdsSolveTw<TF> t)
+{
+    const PresLdsSolve<TF>& a = t.s;
+    const int ky = blockIdx.x*64 + threadIdx.x, row = blockIdx.y;          // rows 0 .. ncol
+    if (ky >= a.jtot) return;
+    const int kxa = (row == a.ncol) ? a.ncol : lds_mode_kx(row, ky, a.jtot, a.ncol);
+    const TF bm = a.bmati[kxa] + a.bmatj[ky];
+    const bool mean = (row == 0 && ky == 0);
+    const size_t col = (size_t)row*a.jtot + ky, lev = (size_t)(a.ncol + 1)*a.jtot;
+    TF inv = TF(1);
+    for (int k=a.kmax-1; k>=t.ksplit; --k)
+    {
+        TF w2 = tdma_diag_lds(a, bm, mean, k);
+        if (k < a.kmax-1) w2 -= uniform_load(a.c, k) * (uniform_load(a.a, k+1) * inv);
+        inv = recip(w2);
+        A3[col + k*lev] = uniform_load(a.a, k) * inv;
+    }
+}
+template<class TF, int BT, int NY, int PHASE>
+__global__ void __launch_bounds__(BT) pres_ysolve_tw_kernel(const PresLdsSolveTw<TF> t)
+{
+    HIP_DYNAMIC_SHARED(LdsUnit, lds_raw);
+    const PresLdsSolve<TF>& a = t.s;
+    const int N = a.jtot, kmax = a.kmax, rp = N, ks = t.ksplit;
+    C2<TF>* D = reinterpret_cast<C2<TF>*>(lds_raw);
+    C2<TF>* T = D + 8*rp;
+    const int ky = threadIdx.x, kx = blockIdx.x >> 1;                          // blockDim.x == jtot
+    T[ky] = a.Ty[ky];
+    const int team = N >> 3, slot = ky / team, l = ky - slot*team;
+    constexpr bool TWC = (NY > 0 && BT <= 512);
+    C2<TF> tw[fft_np(NY)][7];
+    if constexpr (TWC) { lds_barrier(); fft_twiddles_ct<NY>(T, 0, l, tw); }
+    const size_t lev = (size_t)a.ncol*N, wlev = (size_t)(a.ncol + 1)*N;
+    C2<TF>* Sc = a.S + (size_t)kx*N + ky;
+    const TF* Wc = a.W3 + (size_t)kx*N + ky;  const TF* Wc2 = a.W3 + (size_t)a.ncol*N + ky;
+    const TF* Ac = t.A3 + (size_t)kx*N + ky;  const TF* Ac2 = t.A3 + (size_t)a.ncol*N + ky;
+    const bool packed = (kx == 0);
+    const bool two = packed && (ky == 0 || ky == (N >> 1));
+    const bool upper = ky > (N >> 1);
+    const int mir = (N - ky) & (N - 1);
+    const TF bm = a.bmati[lds_mode_kx(kx, ky, N, a.ncol)] + a.bmatj[ky];
+    const TF bm2 = a.bmati[a.ncol] + a.bmatj[ky];
+    const bool mean = (kx == 0 && ky == 0);
+    // the direction as a compile-time constant of the body (the register arrays of a round are then indexed by constants; indexed by
+    // a run-time direction they live in scratch)
+    auto body = [&](auto half_tag) __attribute__((always_inline))
+    {
+    constexpr int half = decltype(half_tag)::value;
+    // this block's levels [kA, kB) in rounds of eight counted from kA
+    const int kA = half ? ks : 0, kB = half ? kmax : ks;
+    const int nround = (kB - kA + 7) >> 3;
+    C2<TF> q[8];
+
+    if constexpr (PHASE == 1)
+    {
+        // ---- elimination: rows of eight levels -> LDS -> transform along y -> sweep towards the split -> S (in place)
+        TF inv = TF(1), inv2 = TF(1); C2<TF> pp{TF(0), TF(0)};
+        const int rd0 = half ? nround-1 : 0, rdstep = half ? -1 : 1;
+#pragma unroll
+        for (int m=0; m<8; ++m) { const int k = kA + (rd0 << 3) + m; q[m] = (k < kB) ? Sc[(size_t)k*lev] : C2<TF>{TF(0), TF(0)}; }
+        for (int n=0, rd=rd0; n<nround; ++n, rd+=rdstep)
+        {
+            const int k0 = kA + (rd << 3);
+#pragma unroll
+            for (int m=0; m<8; ++m) D[m*rp + lds_slot<TF>(ky)] = q[m];
+            if (n + 1 < nround)
+            {
+                const int kn = k0 + (rdstep << 3);
+#pragma unroll
+                for (int m=0; m<8; ++m) if (kn + m < kB) q[m] = Sc[(size_t)(kn + m)*lev];
+            }
+            lds_barrier();
+            { unsigned ll = (unsigned)l, sl = (unsigned)slot; keep_vgpr(ll); keep_vgpr(sl);
+              fft_batch_ct<-1, (BT <= 512), NY, TWC>(D + sl*rp, T, 0, (int)ll, a.ny, true, tw); }
+            if (BT <= 512) lds_barrier();
+            C2<TF> r8[8];
+#pragma unroll
+            for (int m=0; m<8; ++m)
+            {
+                C2<TF> r = D[m*rp + lds_slot<TF>(ky)];
+                if (packed && !two)
+                {
+                    const C2<TF> zm = D[m*rp + lds_slot<TF>(mir)];
+                    r = upper ? C2<TF>{TF(0.5)*(zm.y + r.y), TF(0.5)*(r.x - zm.x)}
+                              : C2<TF>{TF(0.5)*(r.x + zm.x), TF(0.5)*(r.y - zm.y)};
+                }
+                r8[m] = r;
+            }
+            lds_barrier();
+#pragma unroll
+            for (int hh=0; hh<2; ++hh)
+            {
+                const int h = half ? 4 - 4*hh : 4*hh;                 // the group of four nearer to where the sweep comes from first
+                TF dzv[4], av[4], cv[4], rv[4];
+#pragma unroll
+                for (int nn=0; nn<4; ++nn)
+                {
+                    const int kc = (k0 + h + nn < kmax) ? k0 + h + nn : kmax - 1;
+                    dzv[nn] = uniform_load(a.dz, kc); av[nn] = uniform_load(a.a, kc); cv[nn] = uniform_load(a.c, kc); rv[nn] = uniform_load(a.rho, kc);
+                }
+                // the off-diagonal entry of the level the sweep comes from: c[k-1] going up, a[k+1] going down
+                TF oprev = half ? uniform_load(a.a, (k0 + h + 4 < kmax) ? k0 + h + 4 : kmax - 1) : uniform_load(a.c, (k0 + h > 0) ? k0 + h - 1 : 0);
+#pragma unroll
+                for (int n4=0; n4<4; ++n4)
+                {
+                    const int nn = half ? 3 - n4 : n4, m = h + nn, k = k0 + m;
+                    if (k < kB)
+                    {
+                        const TF dz2 = dzv[nn]*dzv[nn];
+                        const TF off = half ? cv[nn] : av[nn];            // multiplies the neighbour already eliminated
+                        const bool first = half ? (k == kmax-1) : (k == 0);
+                        TF w2 = tdma_diag_vals(dz2, rv[nn], av[nn], cv[nn], bm, mean, k, kmax);
+                        C2<TF> r = r8[m];
+                        r.x = dz2 * r.x; r.y = dz2 * r.y;
+                        if (!first)
+                        {
+                            w2 -= off * (oprev * inv);
+                            r.x -= off*pp.x; r.y -= off*pp.y;
+                        }
+                        inv = recip(w2);
+                        r.x *= inv;
+                        if (two)
+                        {
+                            TF w2b = tdma_diag_vals(dz2, rv[nn], av[nn], cv[nn], bm2, false, k, kmax);
+                            if (!first) w2b -= off * (oprev * inv2);
+                            inv2 = recip(w2b);
+                            r.y *= inv2;
+                        }
+                        else r.y *= inv;
+                        pp = r;
+                        Sc[(size_t)k*lev] = r;
+                        if (k == (half ? ks : ks-1)) t.I[((size_t)kx*2 + half)*N + ky] = r;
+                    }
+                    oprev = half ? av[nn] : cv[nn];
+                }
+            }
+        }
+    }
+    else
+    {
+        // ---- where the two sweeps meet: x_m and x_{m-1} from d'_{m-1}, d''_m and the two factors there
+        C2<TF> pp;
+        {
+            const C2<TF> dl = t.I[((size_t)kx*2)*N + ky], du = t.I[((size_t)kx*2 + 1)*N + ky];
+            const TF cp = Wc[(size_t)ks*wlev], ap = Ac[(size_t)ks*wlev];
+            const TF cp2 = two ? Wc2[(size_t)ks*wlev] : cp, ap2 = two ? Ac2[(size_t)ks*wlev] : ap;
+            C2<TF> xm;
+            xm.x = (du.x - ap *dl.x) / (TF(1) - ap *cp);
+            xm.y = (du.y - ap2*dl.y) / (TF(1) - ap2*cp2);
+            pp = half ? C2<TF>{dl.x - cp*xm.x, dl.y - cp2*xm.y} : xm;      // the neighbour's solution this block starts from
+        }
+        // ---- substitution away from the split over eight levels -> LDS -> inverse transform along y -> S
+        TF f3[8], f3b[8];
+        const int rd0 = half ? 0 : nround-1, rdstep = half ? 1 : -1;
+        auto request = [&](int k0)
+        {
+#pragma unroll
+            for (int m=0; m<8; ++m)
+            {
+                const int k = (k0 + m < kB) ? k0 + m : kB - 1;
+                q[m] = Sc[(size_t)k*lev];
+                // going down: x_k = d'_k - c'_k x_{k+1}, c'_k = W3[k+1]; going up: x_k = d''_k - a'_k x_{k-1}
+                f3[m] = half ? Ac[(size_t)k*wlev] : Wc[(size_t)(k + 1)*wlev];
+                f3b[m] = two ? (half ? Ac2[(size_t)k*wlev] : Wc2[(size_t)(k + 1)*wlev]) : f3[m];
+            }
+        };
+        request(kA + (rd0 << 3));
+        for (int n=0, rd=rd0; n<nround; ++n, rd+=rdstep)
+        {
+            const int k0 = kA + (rd << 3);
+#pragma unroll
+            for (int n8=0; n8<8; ++n8)
+            {
+                const int m = half ? n8 : 7 - n8, k = k0 + m;
+                C2<TF> r{TF(0), TF(0)};
+                if (k < kB)
+                {
+                    r.x = q[m].x - f3[m]*pp.x; r.y = q[m].y - f3b[m]*pp.y;
+                    pp = r;
+                }
+                D[m*rp + lds_slot<TF>(ky)] = r;
+            }
+            if (n + 1 < nround) request(k0 + (rdstep << 3));
+            lds_barrier();
+            if (packed)
+            {
+                C2<TF> z[8];
+#pragma unroll
+                for (int m=0; m<8; ++m)
+                {
+                    const C2<TF> own = D[m*rp + lds_slot<TF>(ky)], mv = D[m*rp + lds_slot<TF>(mir)];
+                    z[m] = two ? own : (upper ? C2<TF>{mv.x + own.y, own.x - mv.y} : C2<TF>{own.x - mv.y, own.y + mv.x});
+                }
+                lds_barrier();
+#pragma unroll
+                for (int m=0; m<8; ++m) D[m*rp + lds_slot<TF>(ky)] = z[m];
+                lds_barrier();
+            }
+            { unsigned ll = (unsigned)l, sl = (unsigned)slot; keep_vgpr(ll); keep_vgpr(sl);
+              fft_batch_ct<+1, (BT <= 512), NY, TWC>(D + sl*rp, T, 0, (int)ll, a.ny, true, tw); }
+            if (BT <= 512) lds_barrier();
+#pragma unroll
+            for (int m=0; m<8; ++m) if (k0 + m < kB) Sc[(size_t)(k0 + m)*lev] = D[m*rp + lds_slot<TF>(ky)];
+            lds_barrier();
+        }
+    }
+    };
+    if (blockIdx.x & 1) body(std::integral_constant<int, 1>{}); else body(std::integral_constant<int, 0>{});
 }
 
 // ======================================================================================================================

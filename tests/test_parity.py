@@ -686,6 +686,38 @@ def _lds_form_against_oracle(be, shape, gc, dtype, tol):
         be.lib.mhh_pres_plan_destroy(plan)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pres2_lds_y_stage_with_two_blocks_per_column(be, dtype):
+    """The y stage of the LDS form as a twisted factorisation (csrc/pres_lds.h, 2t: the lower levels eliminated bottom-up by one block,
+    the upper ones top-down by a second, a 2 x 2 system where they meet) against the oracle, like the one-block form: upper halves of
+    one level, of whole and of partial rounds of eight; and against the one-block form within the same tolerance."""
+    tol = 1e-11 if dtype == np.float64 else 2e-4
+    os.environ["MHH_PRES_Y_TWISTED"] = "1"
+    try:
+        for shape in ((16, 64, 17), (32, 16, 24), (16, 8, 37), (64, 32, 40), (128, 32, 16)):
+            _lds_form_against_oracle(be, shape, (3, 3, 1), dtype, tol)
+    finally:
+        os.environ.pop("MHH_PRES_Y_TWISTED", None)
+    # the switch does something: the two forms differ in rounding (and only in rounding)
+    g = cm.grid_2nd(32, 16, 24, gc=(3, 3, 1), dtype=dtype); c = cm.Case(g, rho="random", periodic=True)
+    plan = capi.PLAN()
+    B.ok(be, be.lib.mhh_pres_plan_create(g.host_struct(), 2, ptr(g.dz), ptr(g.dzhi), ptr(g.dzi4), ptr(g.dzhi4), ptr(c.rhoref), ptr(c.rhorefh), C.byref(plan)))
+    out = {}
+    try:
+        for tw in ("0", "1"):
+            d = B.DevCase(be, c); f = d.fields()
+            os.environ["MHH_PRES_LDS"] = "1"; os.environ["MHH_PRES_Y_TWISTED"] = tw
+            try:
+                B.ok(be, be.lib.mhh_pres_exec(plan, d.G, C.byref(f), 0.7, be.stream))
+            finally:
+                os.environ.pop("MHH_PRES_LDS", None); os.environ.pop("MHH_PRES_Y_TWISTED", None)
+            out[tw] = be.host(d.p)
+    finally:
+        be.lib.mhh_pres_plan_destroy(plan)
+    assert not np.array_equal(out["0"], out["1"])
+    assert np.abs(out["0"] - out["1"]).max() <= tol * np.abs(out["0"]).max()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_pres2_lds_form_at_every_instantiated_row_length(dtype):
