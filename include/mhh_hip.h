@@ -276,7 +276,8 @@ int mhh_pres_exec(mhh_pres_plan* plan, const mhh_grid* g, const mhh_fields* f, d
  * profiles/r3_pres_forms.md); MHH_PRES_LDS=1 / 0 selects it wherever the plan has it / never. The stages one by one, for tests:
  * 1 = Pres::input + transform along x (src/pres_2.cxx:156-196, src/pres_4.cxx:256-317, src/fft.cxx:451-497), 2 = transforms along y
  * around the k sweeps (Thomas, src/pres_2.cxx:202-263; the factored 7-band system, src/pres_4.cxx:358-470, 574-730), 3 = transform
- * back along x + p with its ghost cells + Pres::output (src/pres_2.cxx:333-387; src/pres_4.cxx:481-571).                        */
+ * back along x + p with its ghost cells + Pres::output (src/pres_2.cxx:333-387; src/pres_4.cxx:481-571). pres_2 with itot <= 256:
+ * stage 2 runs two blocks per column (a twisted factorisation: bottom-up and top-down eliminations that meet half way; MHH_PRES_Y_TWISTED=0 / 1). */
 int   mhh_pres_lds_stage(mhh_pres_plan* plan, const mhh_grid* g, const mhh_fields* f, double dt, int stage, void* stream);
 int   mhh_pres_plan_has_lds_form(const mhh_pres_plan* plan);
 int   mhh_pres_exec_form(const mhh_pres_plan* plan);   /* what mhh_pres_exec will run: 0 = staged (rocFFT), 1 = transforms in LDS */

@@ -652,7 +652,7 @@ __global__ void __launch_bounds__(BT) pres_ysolve_tw_kernel(const PresLdsSolveTw
             for (int m=0; m<8; ++m) D[m*rp + lds_slot<TF>(ky)] = q[m];
             if (n + 1 < nround)
             {
-                const int kn = k0 + (rdstep << 3);
+                const int kn = k0 + rdstep*8;
 #pragma unroll
                 for (int m=0; m<8; ++m) if (kn + m < kB) q[m] = Sc[(size_t)(kn + m)*lev];
             }
@@ -767,7 +767,7 @@ __global__ void __launch_bounds__(BT) pres_ysolve_tw_kernel(const PresLdsSolveTw
                 }
                 D[m*rp + lds_slot<TF>(ky)] = r;
             }
-            if (n + 1 < nround) request(k0 + (rdstep << 3));
+            if (n + 1 < nround) request(k0 + rdstep*8);
             lds_barrier();
             if (packed)
             {
