@@ -1031,7 +1031,8 @@ static int pres_lds_setup_t(mhh_pres_plan* P)
         MHH_HIP_TRY(hipMalloc(&P->w3l, (size_t)(P->itot/2 + 1)*P->jtot*P->ktot*sizeof(TF)));
         hipLaunchKernelGGL(lds_fft::pres_lds_factor_kernel<TF>, dim3((P->jtot + 63)/64, P->itot/2 + 1), dim3(64), 0, 0, static_cast<TF*>(P->w3l), lds_solve_args<TF>(P));
         // the two-blocks-per-column form of the y stage: its kernels (no scratch), the factors of the top-down half, the buffer where the halves meet
-        if (P->ktot >= 16)
+        // (only where pres_y_twisted() takes it by itself, or when the switch is set at plan creation: its tables are another spectral array)
+        if (P->ktot >= 16 && (P->itot <= 256 || getenv("MHH_PRES_Y_TWISTED")))
         {
             const int ny = ilog2(P->jtot);
             const void* k2[2] = {nullptr, nullptr};
